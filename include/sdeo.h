@@ -1,0 +1,162 @@
+/* libsdeo -- C ABI of the MI355X-native ControlNet / Stable-Diffusion hot path.
+ *
+ * This is the drop-in boundary for the reference's TensorRT seam.  Paths below are relative to the
+ * reference tree (MarToonLi/StableDiffusionEO).
+ *
+ *   reference seam                                               replaced by
+ *   ------------------------------------------------------------ ------------------------------------
+ *   Engine.load / activate / allocate_buffers (Engine.py:99-121)  sdeo_create, sdeo_load_weight,
+ *                                                                 sdeo_finalize_weights, sdeo_configure
+ *   context.set_tensor_address + execute_async_v3                 sdeo_controlnet_forward, sdeo_unet_forward,
+ *     (Engine.py:136-137,145,155-157) for ControlNet.plan /       sdeo_vae_decode, sdeo_apply_model_cfg
+ *     ControlledUnet.plan / Decoder.plan
+ *   cudaStreamBeginCapture / cudaGraphLaunch (Engine.py:139-152)  sdeo_sample_graph_* (hipGraph of one DDIM step)
+ *   p_sample_ddim tail in torch (cldm/ddim_hacked.py:192,208-231) sdeo_cfg_ddim_step
+ *   GroupNormPlugin::enqueue (plugin/groupNormPlugin/              sdeo_groupnorm_nhwc_f16
+ *     groupNormPlugin.cpp:179-228), libplugin.so via ctypes.CDLL
+ *     (onnx2trt_static_plugin.py:7-10)
+ *   CUASSERT / "ERROR: inference failed." (Engine.py:38-44,146)   int return codes + sdeo_last_error()
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; sdeo_last_error() returns the message of
+ *     the calling thread's last failure (the Python Engine maps non-zero to the reference's
+ *     ValueError("ERROR: inference failed.")).
+ *   - all pointers are raw DEVICE pointers unless a parameter name starts with `host_`; `stream` is a
+ *     hipStream_t passed as void* (NULL = default stream).  Nothing here synchronises, allocates or frees
+ *     caller memory, so every call is hipGraph-capturable.
+ *   - fp16 activations are NHWC ("pixel rows" of `ld*` elements); the NCHW fp32 tensors of the reference
+ *     surface are converted at the net-level entry points.
+ *   - a handle is not thread-safe (same as a TensorRT execution context); one handle per GPU / process.
+ */
+#ifndef SDEO_H
+#define SDEO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdeo_handle_s* sdeo_handle;
+
+const char* sdeo_last_error(void);
+int sdeo_version(void);
+
+/* ------------------------------------------------------------------ op-level entry points (used by tests)
+
+ * GroupNorm(+Swish) on NHWC fp16 -- operand contract of the reference plugin (x/y fp16 NHWC, gamma/beta fp32,
+ * attrs epsilon + bSwish, groupNormPlugin.cpp:136-160,291-292) with epsilon actually applied.
+ * workspace: >= sdeo_groupnorm_workspace_bytes(n, h*w, groups) bytes. */
+size_t sdeo_groupnorm_workspace_bytes(int n, int hw, int groups);
+int sdeo_groupnorm_nhwc_f16(void* y, const void* x, const float* gamma, const float* beta, int n, int h, int w, int c,
+                            int groups, float eps, int with_swish, void* workspace, void* stream);
+
+/* conv2d on NHWC fp16 activations with KRSC fp16 weights (implicit GEMM on MFMA).
+ *   y[n][ho][wo][cout] = act( conv(x, w) + bias[cout] + bias2[n][cout] ) * scale + res[n][ho][wo][cout]
+ * cin/cout are the STORED channel counts (cin % 8 == 0, cout % 4 == 0); upsample2x=1 folds a nearest x2
+ * upsample of x in front of the conv.  bias/bias2 fp32 or NULL, res fp16 NHWC or NULL. act: 0 none, 1 SiLU.
+ * workspace (split-K partials): >= sdeo_conv2d_workspace_bytes(...) bytes, may be NULL when that is 0. */
+size_t sdeo_conv2d_workspace_bytes(int n, int h, int w, int cin, int cout, int ksize, int stride, int upsample2x);
+int sdeo_conv2d_nhwc_f16(void* y, const void* x, const void* w_krsc, const float* bias, const float* bias2, const void* res,
+                         int n, int h, int w, int cin, int cout, int ksize, int stride, int upsample2x, int act, float scale,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* GEMM  y[m][n] = act(x[m][k] . w[n][k]^T + bias) * scale + res   (both operands K-contiguous; nn.Linear layout).
+ * out_f32=1 writes fp32.  bias_per_row=1 indexes bias by m.  ld* in elements. */
+size_t sdeo_gemm_workspace_bytes(int m, int n, int k);
+int sdeo_gemm_f16(void* y, int ldy, const void* x, int ldx, const void* w, int ldw, const float* bias, const void* res,
+                  int ldres, int m, int n, int k, int act, float scale, int out_f32, int bias_per_row, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
+/* LayerNorm over the last dim of [rows][c] fp16, fp32 gamma/beta. */
+int sdeo_layernorm_f16(void* y, const void* x, const float* gamma, const float* beta, int rows, int c, float eps,
+                       void* stream);
+
+/* Fused attention O = softmax(Q K^T scale) V.  Q [b][tq][ldq], K [b][tk_stride][ldk] (head h at column h*d),
+ * V TRANSPOSED: vt[(h*d+i)*ldvt + b*tk_stride + j];  O [b][tq][ldo].  Keys >= tk are masked. */
+int sdeo_attention_f16(void* o, int ldo, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int b,
+                       int heads, int tq, int tk, int tk_stride, int d, float scale, void* stream);
+
+/* GEGLU: y[r][0:c] = a[r][0:c] * gelu_erf(a[r][c:2c]) */
+int sdeo_geglu_f16(void* y, const void* a, int rows, int c, void* stream);
+
+/* sinusoidal timestep embedding (util.py:154-174): t int64[b] -> out fp16 [b][dim] */
+int sdeo_timestep_embedding_f16(void* out, const int64_t* t, int b, int dim, void* stream);
+
+/* classifier-free guidance + DDIM update on fp32 latents (ddim_hacked.py:192,208-231).
+ * eps_u may be NULL (no guidance), noise may be NULL (eta = 0), pred_x0 may be NULL. */
+int sdeo_cfg_ddim_step(float* x_prev, float* pred_x0, const float* x, const float* eps_c, const float* eps_u,
+                       const float* noise, float cfg_scale, float a_t, float a_prev, float sigma_t,
+                       float sqrt_one_minus_at, int64_t n, void* stream);
+
+/* layout helpers at the NCHW boundary */
+int sdeo_nchw_f32_to_nhwc_f16(void* y, int ldy, const float* x, int n, int c, int hw, void* stream);
+int sdeo_nhwc_f16_to_nchw_f32(float* y, const void* x, int ldx, int n, int c, int hw, float scale, void* stream);
+int sdeo_oihw_f32_to_krsc_f16(void* y, const float* w, int o, int i, int r, int s, int i_pad, void* stream);
+
+/* ------------------------------------------------------------------ net-level entry points */
+
+typedef struct sdeo_config {
+  /* UNet / ControlNet (cldm_v15.yaml values) */
+  int in_channels, out_channels, hint_channels, model_channels, num_res_blocks;
+  int channel_mult[8];
+  int num_levels;
+  int attention_resolutions[8];
+  int num_attention_resolutions;
+  int num_heads, context_dim, context_len;
+  /* VAE decoder */
+  int vae_ch, vae_out_ch, vae_ch_mult[8], vae_num_levels, vae_num_res_blocks, vae_z_channels;
+  float vae_scale_factor;
+} sdeo_config;
+
+/* Create / destroy an engine instance on the current HIP device. */
+int sdeo_create(const sdeo_config* cfg, sdeo_handle* out);
+int sdeo_destroy(sdeo_handle h);
+
+/* Weights: one call per checkpoint tensor, names exactly as in the reference state dict
+ * ("model.diffusion_model.*", "control_model.*", "first_stage_model.*"; cldm/model.py:12-21).
+ * host_data is a HOST pointer to fp32 data in PyTorch layout (OIHW conv, [out][in] linear).
+ * Unknown names return 0 and are ignored when `strict` is 0.  After the last tensor call
+ * sdeo_finalize_weights (fails listing what is missing). */
+int sdeo_load_weight(sdeo_handle h, const char* name, const float* host_data, const int64_t* dims, int ndim, int strict);
+int sdeo_finalize_weights(sdeo_handle h);
+/* Number of expected tensors and the i-th expected name/shape (ndim<=4), for loaders and tests. */
+int sdeo_num_weights(sdeo_handle h);
+int sdeo_weight_info(sdeo_handle h, int i, const char** name, int64_t dims[4], int* ndim);
+
+/* Fix the problem size (allocate_buffers equivalent): n = images per call of the *_forward functions
+ * (the CFG pair counts as 2), latent h x w.  Allocates the activation arena once. */
+int sdeo_configure(sdeo_handle h, int n, int latent_h, int latent_w);
+
+/* ControlNet.forward (cldm/cldm.py:284-305).  NCHW fp32 at the boundary:
+ *   x_noisy [n][4][h][w], hint [n][3][8h][8w] in [0,1], timesteps int64 [n], context [n][77][768],
+ *   controls[13]: NCHW fp32 outputs in the reference's binding order (export_onnx_all.py:242-256).
+ * hint_is_new=1 recomputes the input_hint_block (timestep independent); 0 reuses the cached result. */
+int sdeo_controlnet_forward(sdeo_handle h, const float* x_noisy, const float* hint, const int64_t* timesteps,
+                            const float* context, float* const* controls, int hint_is_new, void* stream);
+
+/* ControlledUnetModel.forward (cldm/cldm.py:22-45).  controls may be NULL (c_concat=None branch);
+ * control_scales fp32[13] host pointer or NULL (= 1.0); only_mid_control as in the reference. */
+int sdeo_unet_forward(sdeo_handle h, const float* x_noisy, const int64_t* timesteps, const float* context,
+                      const float* const* controls, const float* host_control_scales, int only_mid_control, float* eps,
+                      void* stream);
+
+/* ControlLDM.apply_model (cldm/cldm.py:328-341) without the NCHW fp32 round trip of the 13 control tensors:
+ * ControlNet -> scaled controls -> UNet, all fp16 NHWC inside the arena.  hint may be NULL (UNet only). */
+int sdeo_apply_model(sdeo_handle h, const float* x_noisy, const float* hint, const int64_t* timesteps,
+                     const float* context, const float* host_control_scales, int only_mid_control, int hint_is_new,
+                     float* eps, void* stream);
+
+/* decode_first_stage: z/scale_factor -> post_quant_conv -> Decoder (model.py:619-652).
+ * z [n][4][h][w] fp32 NCHW -> images [n][3][8h][8w] fp32 NCHW in [-1,1]; images_u8 (optional, may be NULL)
+ * additionally receives the NHWC uint8 post-process of canny2image_torch.py:68. n must be <= configured n. */
+int sdeo_vae_decode(sdeo_handle h, const float* z, int n, float* images, uint8_t* images_u8, void* stream);
+
+/* bytes of device memory the handle owns (weights + arena) */
+size_t sdeo_device_bytes(sdeo_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDEO_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of libsdeo.so (the C ABI in include/sdeo.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent, loading
+raises immediately (the reference silently falls back to PyTorch when a .plan is missing,
+`cldm_trt/ddim_hacked.py:22-23,35-36`; we deliberately do not)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsdeo.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "sdeo.h")
+
+_lib = None
+
+MAX_LEVELS = 8
+
+
+class SdeoConfig(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int), ("out_channels", C.c_int), ("hint_channels", C.c_int),
+        ("model_channels", C.c_int), ("num_res_blocks", C.c_int),
+        ("channel_mult", C.c_int * MAX_LEVELS), ("num_levels", C.c_int),
+        ("attention_resolutions", C.c_int * MAX_LEVELS), ("num_attention_resolutions", C.c_int),
+        ("num_heads", C.c_int), ("context_dim", C.c_int), ("context_len", C.c_int),
+        ("vae_ch", C.c_int), ("vae_out_ch", C.c_int), ("vae_ch_mult", C.c_int * MAX_LEVELS),
+        ("vae_num_levels", C.c_int), ("vae_num_res_blocks", C.c_int), ("vae_z_channels", C.c_int),
+        ("vae_scale_factor", C.c_float),
+    ]
+
+
+def declared_symbols(header: str = HEADER):
+    """Names of every function include/sdeo.h declares (used by the CPU export test)."""
+    txt = open(header).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sdeo_[a-z0-9_]+)\s*\(", txt)))
+
+
+class SdeoError(RuntimeError):
+    pass
+
+
+def load(path: str = LIB_PATH):
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise SdeoError(f"{path} not found: build it with `python -m stablediffusioneo_amd.build` "
+                        f"(there is no CPU / PyTorch fallback for the HIP path)")
+    lib = C.CDLL(path)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    if missing:
+        raise SdeoError(f"libsdeo.so does not export {missing}")
+    lib.sdeo_last_error.restype = C.c_char_p
+    for name in ("sdeo_groupnorm_workspace_bytes", "sdeo_conv2d_workspace_bytes", "sdeo_gemm_workspace_bytes",
+                 "sdeo_device_bytes"):
+        getattr(lib, name).restype = C.c_size_t
+    lib.sdeo_device_bytes.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "sdeo"):
+    if rc != 0:
+        msg = load().sdeo_last_error().decode(errors="replace")
+        raise SdeoError(f"{what} failed: {msg}")
+
+
+def ptr(t):
+    """Raw device (or host) pointer of a torch tensor as c_void_p; None -> NULL."""
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())
+
+
+def cur_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

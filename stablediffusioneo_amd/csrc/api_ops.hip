@@ -1,0 +1,136 @@
+// C ABI: error convention and the op-level entry points declared in include/sdeo.h.
+#include <stdarg.h>
+
+#include "../../include/sdeo.h"
+#include "kernels.h"
+
+namespace sdeo {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+int fail(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return 1;
+}
+
+}  // namespace sdeo
+
+using namespace sdeo;
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" {
+
+const char* sdeo_last_error(void) { return g_last_error.c_str(); }
+int sdeo_version(void) { return 100; }
+
+size_t sdeo_groupnorm_workspace_bytes(int n, int hw, int groups) {
+  return (size_t)n * gn_chunks(hw) * groups * 2 * sizeof(float);
+}
+
+int sdeo_groupnorm_nhwc_f16(void* y, const void* x, const float* gamma, const float* beta, int n, int h, int w, int c,
+                            int groups, float eps, int with_swish, void* workspace, void* stream) {
+  return groupnorm_nhwc((f16*)y, c, (const f16*)x, c, gamma, beta, n, h * w, c, groups, eps, with_swish, (float*)workspace,
+                        S(stream));
+}
+
+static int fill_conv(ConvGemm& p, int n, int h, int w, int cin, int cout, int ksize, int stride, int upsample2x) {
+  SDEO_CHECK(ksize == 1 || ksize == 3, "conv2d: ksize %d unsupported", ksize);
+  SDEO_CHECK(stride == 1 || stride == 2, "conv2d: stride %d unsupported", stride);
+  const int pad = ksize / 2;
+  const int hv = upsample2x ? 2 * h : h, wv = upsample2x ? 2 * w : w;
+  p.B = n; p.Hi = h; p.Wi = w; p.Cin = cin;
+  p.R = p.S = ksize; p.stride = stride; p.pad = pad; p.ups = upsample2x;
+  p.Ho = (hv + 2 * pad - ksize) / stride + 1;
+  p.Wo = (wv + 2 * pad - ksize) / stride + 1;
+  p.M = n * p.Ho * p.Wo; p.N = cout; p.K = ksize * ksize * cin;
+  p.ldx = cin; p.ldw = p.K; p.ldy = cout; p.ldres = cout; p.ld_bias2 = cout;
+  return 0;
+}
+
+size_t sdeo_conv2d_workspace_bytes(int n, int h, int w, int cin, int cout, int ksize, int stride, int upsample2x) {
+  ConvGemm p;
+  if (fill_conv(p, n, h, w, cin, cout, ksize, stride, upsample2x)) return 0;
+  return conv_gemm_workspace_bytes(p);
+}
+
+int sdeo_conv2d_nhwc_f16(void* y, const void* x, const void* w_krsc, const float* bias, const float* bias2, const void* res,
+                         int n, int h, int w, int cin, int cout, int ksize, int stride, int upsample2x, int act, float scale,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  ConvGemm p;
+  if (int rc = fill_conv(p, n, h, w, cin, cout, ksize, stride, upsample2x)) return rc;
+  p.x = (const f16*)x; p.w = (const f16*)w_krsc; p.y = (f16*)y; p.bias = bias; p.bias2 = bias2; p.res = (const f16*)res;
+  p.act = act; p.scale = scale; p.workspace = (float*)workspace; p.workspace_bytes = workspace_bytes;
+  return conv_gemm(p, S(stream));
+}
+
+static void fill_gemm(ConvGemm& p, int m, int n, int k) {
+  p.B = m; p.Hi = p.Wi = p.Ho = p.Wo = 1; p.Cin = k; p.R = p.S = 1; p.stride = 1; p.pad = 0;
+  p.M = m; p.N = n; p.K = k;
+}
+
+size_t sdeo_gemm_workspace_bytes(int m, int n, int k) {
+  ConvGemm p;
+  fill_gemm(p, m, n, k);
+  return conv_gemm_workspace_bytes(p);
+}
+
+int sdeo_gemm_f16(void* y, int ldy, const void* x, int ldx, const void* w, int ldw, const float* bias, const void* res,
+                  int ldres, int m, int n, int k, int act, float scale, int out_f32, int bias_per_row, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+  ConvGemm p;
+  fill_gemm(p, m, n, k);
+  p.x = (const f16*)x; p.w = (const f16*)w; p.bias = bias; p.res = (const f16*)res;
+  if (out_f32) p.y32 = (float*)y; else p.y = (f16*)y;
+  p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldres = ldres;
+  p.act = act; p.scale = scale; p.bias_per_row = bias_per_row;
+  p.workspace = (float*)workspace; p.workspace_bytes = workspace_bytes;
+  return conv_gemm(p, S(stream));
+}
+
+int sdeo_layernorm_f16(void* y, const void* x, const float* gamma, const float* beta, int rows, int c, float eps,
+                       void* stream) {
+  return layernorm((f16*)y, c, (const f16*)x, c, gamma, beta, rows, c, eps, S(stream));
+}
+
+int sdeo_attention_f16(void* o, int ldo, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int b,
+                       int heads, int tq, int tk, int tk_stride, int d, float scale, void* stream) {
+  return attention((f16*)o, ldo, (const f16*)q, ldq, (const f16*)k, ldk, (const f16*)vt, ldvt, b, heads, tq, tk, tk_stride, d,
+                   scale, S(stream));
+}
+
+int sdeo_geglu_f16(void* y, const void* a, int rows, int c, void* stream) {
+  return geglu((f16*)y, c, (const f16*)a, 2 * c, rows, c, S(stream));
+}
+
+int sdeo_timestep_embedding_f16(void* out, const int64_t* t, int b, int dim, void* stream) {
+  return timestep_embedding((f16*)out, t, b, dim, S(stream));
+}
+
+int sdeo_cfg_ddim_step(float* x_prev, float* pred_x0, const float* x, const float* eps_c, const float* eps_u,
+                       const float* noise, float cfg_scale, float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at,
+                       int64_t n, void* stream) {
+  return cfg_ddim_step(x_prev, pred_x0, x, eps_c, eps_u, noise, cfg_scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, n,
+                       S(stream));
+}
+
+int sdeo_nchw_f32_to_nhwc_f16(void* y, int ldy, const float* x, int n, int c, int hw, void* stream) {
+  return nchw_f32_to_nhwc_f16((f16*)y, ldy, x, n, c, hw, S(stream));
+}
+
+int sdeo_nhwc_f16_to_nchw_f32(float* y, const void* x, int ldx, int n, int c, int hw, float scale, void* stream) {
+  return nhwc_f16_to_nchw_f32(y, (const f16*)x, ldx, n, c, hw, scale, S(stream));
+}
+
+int sdeo_oihw_f32_to_krsc_f16(void* y, const float* w, int o, int i, int r, int s, int i_pad, void* stream) {
+  return oihw_f32_to_ohwi_f16((f16*)y, w, o, i, r, s, i_pad, S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+// Internal helpers shared by the HIP translation units of libsdeo (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace sdeo {
+
+// error convention: every C entry point returns 0 on success; the message of the last failure
+// is kept per thread and returned by sdeo_last_error() (replaces the reference's CUASSERT /
+// PLUGIN_FAIL macros, Engine.py:38-44, plugin/common/checkMacrosPlugin.cpp).
+void set_error(const std::string& msg);
+int fail(const char* fmt, ...);
+
+#define SDEO_CHECK(cond, ...)                       \
+  do {                                              \
+    if (!(cond)) return ::sdeo::fail(__VA_ARGS__);  \
+  } while (0)
+
+#define SDEO_HIP(expr)                                                                   \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess)                                                                \
+      return ::sdeo::fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+
+}  // namespace sdeo

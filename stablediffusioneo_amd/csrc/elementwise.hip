@@ -1,0 +1,225 @@
+// Memory-bound elementwise / layout kernels of the CNSD path (gfx950): 16-byte vector accesses,
+// grid-stride loops, fp32 math.
+#include "kernels.h"
+
+namespace sdeo {
+
+static inline dim3 grid_for(int64_t work_items) {
+  int64_t b = cdiv64(work_items, 256);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
+// GEGLU (`attention.py:49-56`): y = a[:, :C] * gelu(a[:, C:]) with the exact erf GELU (F.gelu default).
+__global__ __launch_bounds__(256) void geglu_kernel(f16* __restrict__ y, int ldy, const f16* __restrict__ a, int lda,
+                                                    int64_t rows, int C) {
+  const int nvec = C / 8;
+  const int64_t total = rows * nvec;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / nvec;
+    const int v = (int)(i - r * nvec);
+    const f16x8 xv = *reinterpret_cast<const f16x8*>(a + r * lda + v * 8);
+    const f16x8 gv = *reinterpret_cast<const f16x8*>(a + r * lda + C + v * 8);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float g = (float)gv[j];
+      const float ge = 0.5f * g * (1.0f + erff(g * 0.70710678118654752440f));
+      o[j] = (f16)((float)xv[j] * ge);
+    }
+    *reinterpret_cast<f16x8*>(y + r * ldy + v * 8) = o;
+  }
+}
+
+int geglu(f16* y, int ldy, const f16* a, int lda, int rows, int C, hipStream_t stream) {
+  SDEO_CHECK(y && a && rows > 0 && C > 0 && C % 8 == 0 && ldy % 8 == 0 && lda % 8 == 0, "geglu: bad operand");
+  hipLaunchKernelGGL(geglu_kernel, grid_for((int64_t)rows * (C / 8)), dim3(256), 0, stream, y, ldy, a, lda, (int64_t)rows, C);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void add_scaled_kernel(f16* __restrict__ y, int ldy, const f16* __restrict__ a, int lda,
+                                                         const f16* __restrict__ b, int ldb, float scale, int64_t rows,
+                                                         int C) {
+  const int nvec = C / 8;
+  const int64_t total = rows * nvec;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / nvec;
+    const int v = (int)(i - r * nvec);
+    f16x8 av = *reinterpret_cast<const f16x8*>(a + r * lda + v * 8);
+    if (b) {
+      const f16x8 bv = *reinterpret_cast<const f16x8*>(b + r * ldb + v * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) av[j] = (f16)((float)av[j] + (float)bv[j] * scale);
+    }
+    *reinterpret_cast<f16x8*>(y + r * ldy + v * 8) = av;
+  }
+}
+
+int add_scaled(f16* y, int ldy, const f16* a, int lda, const f16* b, int ldb, float scale, int rows, int C,
+               hipStream_t stream) {
+  SDEO_CHECK(y && a && rows > 0 && C > 0 && C % 8 == 0 && ldy % 8 == 0 && lda % 8 == 0 && (!b || ldb % 8 == 0),
+             "add_scaled: bad operand");
+  hipLaunchKernelGGL(add_scaled_kernel, grid_for((int64_t)rows * (C / 8)), dim3(256), 0, stream, y, ldy, a, lda, b, ldb,
+                     scale, (int64_t)rows, C);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+// timestep_embedding (`util.py:154-174`): [cos(t*f_i), sin(t*f_i)], f_i = exp(-ln(1e4) * i / half)
+__global__ void timestep_embedding_kernel(f16* __restrict__ out, const int64_t* __restrict__ t, int B, int dim) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, k = i - b * half;
+  const float freq = expf(-9.210340371976184f * (float)k / (float)half);
+  const float arg = (float)t[b] * freq;
+  out[(size_t)b * dim + k] = (f16)cosf(arg);
+  out[(size_t)b * dim + half + k] = (f16)sinf(arg);
+  if ((dim & 1) && k == 0) out[(size_t)b * dim + dim - 1] = (f16)0.f;
+}
+
+int timestep_embedding(f16* out, const int64_t* t, int B, int dim, hipStream_t stream) {
+  SDEO_CHECK(out && t && B > 0 && dim > 1, "timestep_embedding: bad operand");
+  const int n = B * (dim / 2);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, out, t, B, dim);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void silu_kernel(f16* __restrict__ y, const f16* __restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = (f16)silu_f((float)x[i]);
+}
+
+int silu(f16* y, const f16* x, int64_t n, hipStream_t stream) {
+  SDEO_CHECK(y && x && n > 0, "silu: bad operand");
+  hipLaunchKernelGGL(silu_kernel, grid_for(n), dim3(256), 0, stream, y, x, n);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+// NCHW fp32 -> NHWC fp16 with channel padding to ldy (pad channels written as 0). One thread per pixel.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(f16* __restrict__ y, int ldy, const float* __restrict__ x, int B,
+                                                           int C, int HW) {
+  const int64_t total = (int64_t)B * HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / HW;
+    const int64_t pix = i - b * HW;
+    for (int c = 0; c < ldy; ++c)
+      y[i * ldy + c] = c < C ? (f16)x[(b * C + c) * HW + pix] : (f16)0.f;
+  }
+}
+
+int nchw_f32_to_nhwc_f16(f16* y, int ldy, const float* x, int B, int C, int HW, hipStream_t stream) {
+  SDEO_CHECK(y && x && B > 0 && C > 0 && HW > 0 && ldy >= C, "nchw_f32_to_nhwc_f16: bad operand");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid_for((int64_t)B * HW), dim3(256), 0, stream, y, ldy, x, B, C, HW);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+// NHWC fp16 -> NCHW fp32 (times scale). Thread per (b, c, pix) element, pix fastest => coalesced writes.
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(float* __restrict__ y, const f16* __restrict__ x, int ldx, int B,
+                                                           int C, int HW, float scale) {
+  const int64_t total = (int64_t)B * C * HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t pix = i % HW;
+    const int64_t bc = i / HW;
+    const int64_t c = bc % C, b = bc / C;
+    y[i] = (float)x[(b * HW + pix) * ldx + c] * scale;
+  }
+}
+
+int nhwc_f16_to_nchw_f32(float* y, const f16* x, int ldx, int B, int C, int HW, float scale, hipStream_t stream) {
+  SDEO_CHECK(y && x && B > 0 && C > 0 && HW > 0 && ldx >= C, "nhwc_f16_to_nchw_f32: bad operand");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid_for((int64_t)B * C * HW), dim3(256), 0, stream, y, x, ldx, B, C, HW, scale);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+// post-process (`canny2image_torch.py:68`): (x*127.5+127.5).clip(0,255).astype(uint8), truncation like numpy
+__global__ __launch_bounds__(256) void to_u8_kernel(uint8_t* __restrict__ y, const f16* __restrict__ x, int ldx,
+                                                    int64_t pixels, int C) {
+  const int64_t total = pixels * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t pix = i / C;
+    const int c = (int)(i - pix * C);
+    float v = (float)x[pix * ldx + c] * 127.5f + 127.5f;
+    v = fminf(fmaxf(v, 0.f), 255.f);
+    y[i] = (uint8_t)v;
+  }
+}
+
+int nhwc_f16_to_nhwc_u8(uint8_t* y, const f16* x, int ldx, int64_t pixels, int C, hipStream_t stream) {
+  SDEO_CHECK(y && x && pixels > 0 && C > 0 && ldx >= C, "nhwc_f16_to_nhwc_u8: bad operand");
+  hipLaunchKernelGGL(to_u8_kernel, grid_for(pixels * C), dim3(256), 0, stream, y, x, ldx, pixels, C);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+// weights: fp32 OIHW -> fp16 O,R,S,Ipad (K-contiguous KRSC, zero-padded input channels)
+__global__ __launch_bounds__(256) void oihw_to_ohwi_kernel(f16* __restrict__ y, const float* __restrict__ w, int O, int I,
+                                                           int R, int S, int Ipad) {
+  const int64_t total = (int64_t)O * R * S * Ipad;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % Ipad);
+    const int64_t t = i / Ipad;
+    const int s = (int)(t % S);
+    const int64_t t2 = t / S;
+    const int r = (int)(t2 % R);
+    const int64_t o = t2 / R;
+    y[i] = c < I ? (f16)w[((o * I + c) * R + r) * S + s] : (f16)0.f;
+  }
+}
+
+int oihw_f32_to_ohwi_f16(f16* y, const float* w, int O, int I, int R, int S, int Ipad, hipStream_t stream) {
+  SDEO_CHECK(y && w && O > 0 && I > 0 && R > 0 && S > 0 && Ipad >= I, "oihw_f32_to_ohwi_f16: bad operand");
+  hipLaunchKernelGGL(oihw_to_ohwi_kernel, grid_for((int64_t)O * R * S * Ipad), dim3(256), 0, stream, y, w, O, I, R, S, Ipad);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void f32_to_f16_kernel(f16* __restrict__ y, const float* __restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = (f16)x[i];
+}
+
+int f32_to_f16(f16* y, const float* x, int64_t n, hipStream_t stream) {
+  SDEO_CHECK(y && x && n > 0, "f32_to_f16: bad operand");
+  hipLaunchKernelGGL(f32_to_f16_kernel, grid_for(n), dim3(256), 0, stream, y, x, n);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+// CFG combine + DDIM update (`cldm/ddim_hacked.py:192,208-231`), eps-parameterisation, fp32 NCHW latents.
+//   e = eps_u + s*(eps_c - eps_u);  pred_x0 = (x - sqrt(1-a_t) e)/sqrt(a_t)
+//   x_prev = sqrt(a_prev) pred_x0 + sqrt(1 - a_prev - sigma^2) e + sigma * noise
+__global__ __launch_bounds__(256) void cfg_ddim_kernel(float* __restrict__ x_prev, float* __restrict__ pred_x0,
+                                                       const float* __restrict__ x, const float* __restrict__ ec,
+                                                       const float* __restrict__ eu, const float* __restrict__ noise,
+                                                       float s, float rsqrt_at, float sqrt_aprev, float dir_coef, float sigma,
+                                                       float sqrt_1m_at, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float c = ec[i];
+    const float e = eu ? eu[i] + s * (c - eu[i]) : c;
+    const float p0 = (x[i] - sqrt_1m_at * e) * rsqrt_at;
+    float xp = sqrt_aprev * p0 + dir_coef * e;
+    if (noise) xp += sigma * noise[i];
+    x_prev[i] = xp;
+    if (pred_x0) pred_x0[i] = p0;
+  }
+}
+
+int cfg_ddim_step(float* x_prev, float* pred_x0, const float* x, const float* eps_c, const float* eps_u, const float* noise,
+                  float cfg_scale, float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at, int64_t n,
+                  hipStream_t stream) {
+  SDEO_CHECK(x_prev && x && eps_c && n > 0, "cfg_ddim_step: bad operand");
+  SDEO_CHECK(a_t > 0.f && (1.f - a_prev - sigma_t * sigma_t) >= 0.f, "cfg_ddim_step: invalid schedule a_t=%g a_prev=%g sigma=%g",
+             a_t, a_prev, sigma_t);
+  hipLaunchKernelGGL(cfg_ddim_kernel, grid_for(n), dim3(256), 0, stream, x_prev, pred_x0, x, eps_c, eps_u, noise, cfg_scale,
+                     1.0f / sqrtf(a_t), sqrtf(a_prev), sqrtf(1.f - a_prev - sigma_t * sigma_t), sigma_t, sqrt_one_minus_at, n);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace sdeo

@@ -1,0 +1,85 @@
+// Host-side launchers of the hand-written gfx950 kernels.  All are asynchronous on `stream`,
+// never allocate and never synchronise (hipGraph-capturable).
+#pragma once
+#include "common.h"
+
+namespace sdeo {
+
+// ------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution / GEMM on MFMA:   Y[M][N] = epi( sum_k A(m,k) * W[n][k] )
+//   A(m,k) is gathered on the fly from an NHWC fp16 tensor (im2col never materialised):
+//   m -> (b, ho, wo), k -> (r, s, c);  R=S=1 gives a plain row-major GEMM (Linear / conv1x1).
+//   W is K-contiguous: [N][R][S][Cin] (KRSC) == nn.Linear's native [out][in].
+//   epilogue:  v = acc + bias[n] + bias2[b][n];  v = act(v);  v = v*scale + res[m][n]
+// ------------------------------------------------------------------------------------------
+struct ConvGemm {
+  const f16* x = nullptr;      // activations, pixel stride ldx elements
+  const f16* w = nullptr;      // weights [N][K], row stride ldw
+  f16* y = nullptr;            // fp16 output (row stride ldy) ...
+  float* y32 = nullptr;        // ... or fp32 output when set
+  const float* bias = nullptr;   // [N]   (or [M] when bias_per_row)
+  const float* bias2 = nullptr;  // [B][ld_bias2], indexed by the batch of row m (time-embedding add)
+  const f16* res = nullptr;      // residual [M][ldres]
+  float* workspace = nullptr;    // split-K partials, >= splitk*M*N floats
+  size_t workspace_bytes = 0;
+  int M = 0, N = 0, K = 0;
+  int B = 1, Hi = 1, Wi = 1, Cin = 0;  // source tensor geometry (Cin = channels consumed per tap)
+  int Ho = 1, Wo = 1, R = 1, S = 1, stride = 1, pad = 0;
+  int ups = 0;                 // 1: the conv sees the source nearest-upsampled x2 (Upsample folded in)
+  int ldx = 0, ldw = 0, ldy = 0, ldres = 0, ld_bias2 = 0;
+  int act = 0;                 // 0 none, 1 SiLU
+  int bias_per_row = 0;
+  float scale = 1.0f;
+  int force_tile = -1;         // testing hook: tile config index
+  int force_splitk = 0;
+};
+int conv_gemm(const ConvGemm& p, hipStream_t stream);
+size_t conv_gemm_workspace_bytes(const ConvGemm& p);
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm (NHWC fp16, fp32 statistics, eps honoured) + optional SiLU; two launches:
+// per-chunk partial sums, then normalise.  `partials` >= B*gn_chunks(HW)*groups*2 floats.
+// ------------------------------------------------------------------------------------------
+int gn_chunks(int HW);
+int groupnorm_nhwc(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const float* beta, int B, int HW, int C,
+                   int groups, float eps, int with_silu, float* partials, hipStream_t stream);
+
+// LayerNorm over the last dim of [rows][C] fp16 (two-pass in registers, fp32 math).
+int layernorm(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const float* beta, int rows, int C, float eps,
+              hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------
+// Fused attention  O = softmax(Q K^T * scale) V   (flash-style, scores never materialised)
+//   Q[(b*Tq+t)*ldq + h*d + i], K[(b*TkS+j)*ldk + h*d + i], Vt[(h*d+i)*ldvt + b*TkS + j]
+//   O[(b*Tq+t)*ldo + h*d + i];  keys j >= Tk are masked;  TkS = key rows per batch (stride).
+// ------------------------------------------------------------------------------------------
+int attention(f16* o, int ldo, const f16* q, int ldq, const f16* k, int ldk, const f16* vt, int ldvt, int B, int H,
+              int Tq, int Tk, int TkS, int d, float scale, hipStream_t stream);
+
+// row softmax: fp32 scores [rows][ld] -> fp16 probabilities (VAE single-head attention)
+int softmax_rows(f16* p, int ldp, const float* s, int lds, int rows, int cols, float scale, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------
+// elementwise / layout kernels
+// ------------------------------------------------------------------------------------------
+// y[m][0:C] = a[m][0:C] * gelu(a[m][C:2C])      (GEGLU, exact erf GELU)
+int geglu(f16* y, int ldy, const f16* a, int lda, int rows, int C, hipStream_t stream);
+// y = a + b*scale (b may be null), fp16, strided rows of C channels
+int add_scaled(f16* y, int ldy, const f16* a, int lda, const f16* b, int ldb, float scale, int rows, int C,
+               hipStream_t stream);
+// sinusoidal timestep embedding (util.py:154-174): out[b][dim] fp16
+int timestep_embedding(f16* out, const int64_t* t, int B, int dim, hipStream_t stream);
+int silu(f16* y, const f16* x, int64_t n, hipStream_t stream);
+// layout / dtype conversion at the NCHW boundary
+int nchw_f32_to_nhwc_f16(f16* y, int ldy, const float* x, int B, int C, int HW, hipStream_t stream);
+int nhwc_f16_to_nchw_f32(float* y, const f16* x, int ldx, int B, int C, int HW, float scale, hipStream_t stream);
+int nhwc_f16_to_nhwc_u8(uint8_t* y, const f16* x, int ldx, int64_t pixels, int C, hipStream_t stream);
+// weights: fp32 [O][I][R][S] -> fp16 [O][R][S][Ipad]
+int oihw_f32_to_ohwi_f16(f16* y, const float* w, int O, int I, int R, int S, int Ipad, hipStream_t stream);
+int f32_to_f16(f16* y, const float* x, int64_t n, hipStream_t stream);
+// classifier-free guidance + DDIM update on NCHW fp32 latents (ddim_hacked.py:192,208-231)
+int cfg_ddim_step(float* x_prev, float* pred_x0, const float* x, const float* eps_c, const float* eps_u, const float* noise,
+                  float cfg_scale, float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at, int64_t n,
+                  hipStream_t stream);
+
+}  // namespace sdeo

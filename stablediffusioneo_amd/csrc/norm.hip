@@ -1,0 +1,280 @@
+// GroupNorm(+SiLU), LayerNorm and row-softmax for gfx950.
+//
+// GroupNorm replaces the reference's TensorRT plugin (`plugin/groupNormPlugin/groupNormKernel.cu:49-238`,
+// `groupNormPlugin.cpp:179-228`): same operand contract (NHWC fp16 in/out, fp32 gamma/beta, optional Swish),
+// but (a) epsilon is honoured (the plugin drops it), (b) any channel count with C % 8 == 0
+// and C % groups == 0 is accepted (the plugin hard-codes 320/480/256/128-channel blocks), (c) the per-group
+// statistics are a deterministic two-level reduction (per-thread fp32 partials -> LDS -> per-chunk slab ->
+// fixed-order sum) instead of atomicAdd into a memset workspace, so results are bitwise reproducible.
+// Numerics follow PyTorch's F.group_norm (`util.py:217-219`, `attention.py:88-89`): fp32 mean / biased
+// variance over (C/G)*H*W elements, y = (x-mean)*rsqrt(var+eps)*gamma+beta.
+#include "kernels.h"
+
+namespace sdeo {
+
+// statistics chunks per image: enough blocks to fill 256 CUs at the 64x64 level, capped so the
+// second-level sum stays short
+int gn_chunks(int HW) { const int c = cdiv(HW, 16); return c > 256 ? 256 : c; }
+
+// Channel vectors (8 x fp16 = 16 B) handled by one block: the largest divisor of C/8 that is <= 256 and
+// covers whole groups.  Returns 0 when no such split exists.
+static int gn_vec_per_block(int C, int groups) {
+  const int nvec = C / 8, cpg = C / groups;
+  for (int parts = 1; parts <= nvec; ++parts) {
+    if (nvec % parts) continue;
+    const int nvb = nvec / parts;
+    if (nvb > 256) continue;
+    if ((nvb * 8) % cpg) continue;
+    return nvb;
+  }
+  return 0;
+}
+
+// grid: (chunks, channel-parts, B).  Thread (prow, cv) walks pixels prow, prow+P, ... of its chunk with a
+// fixed 8-channel vector cv, so a wave reads whole contiguous NHWC rows.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x, int ldx, int HW, int C, int cpg,
+                                                       int nvb, float* __restrict__ partials, int nchunks,
+                                                       int groups, int ppc) {
+  __shared__ float s_sum[256 * 8];
+  __shared__ float s_sq[256 * 8];
+  const int tid = threadIdx.x;
+  const int P = 256 / nvb;
+  const int cv = tid % nvb, prow = tid / nvb;
+  const int chunk = blockIdx.x, part = blockIdx.y, b = blockIdx.z;
+  const int c0 = (part * nvb + cv) * 8;
+  const int pbeg = chunk * ppc;
+  const int pend = min(HW, pbeg + ppc);
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+  if (prow < P) {
+    const f16* base = x + ((size_t)b * HW) * ldx + c0;
+    for (int pix = pbeg + prow; pix < pend; pix += P) {
+      const f16x8 v = *reinterpret_cast<const f16x8*>(base + (size_t)pix * ldx);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)v[j];
+        s[j] += f;
+        q[j] += f * f;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s_sum[tid * 8 + j] = s[j]; s_sq[tid * 8 + j] = q[j]; }
+  __syncthreads();
+  // one thread per group of this block: fixed-order sum over pixel rows and the group's channels
+  const int gpb = nvb * 8 / cpg;    // groups per block
+  if (tid < gpb) {
+    float ts = 0.f, tq = 0.f;
+    const int cbeg = tid * cpg;     // channel offset inside the block's channel slab
+    for (int pr = 0; pr < P; ++pr)
+      for (int c = cbeg; c < cbeg + cpg; ++c) {
+        const int idx = (pr * nvb + (c >> 3)) * 8 + (c & 7);
+        ts += s_sum[idx];
+        tq += s_sq[idx];
+      }
+    const int g = part * gpb + tid;
+    float* dst = partials + (((size_t)b * nchunks + chunk) * groups + g) * 2;
+    dst[0] = ts;
+    dst[1] = tq;
+  }
+}
+
+// grid: (chunks, channel-parts, B): fold mean/rstd/gamma/beta into per-channel a,b in LDS, then y = x*a+b.
+__global__ __launch_bounds__(256) void gn_apply_kernel(f16* __restrict__ y, int ldy, const f16* __restrict__ x, int ldx,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int HW, int C, int cpg, int nvb, const float* __restrict__ partials,
+                                                       int nchunks, int groups, float eps, int with_silu, int ppc) {
+  __shared__ float s_a[256 * 8];
+  __shared__ float s_b[256 * 8];
+  __shared__ float s_mean[64];
+  __shared__ float s_rstd[64];
+  const int tid = threadIdx.x;
+  const int P = 256 / nvb;
+  const int cv = tid % nvb, prow = tid / nvb;
+  const int chunk = blockIdx.x, part = blockIdx.y, b = blockIdx.z;
+  const int gpb = nvb * 8 / cpg;
+  {
+    // second-level reduction over chunks: tpg threads per group, fixed order => deterministic
+    const int tpg = 256 / gpb;
+    const int gl = tid / tpg, l = tid - gl * tpg;
+    float ts = 0.f, tq = 0.f;
+    if (gl < gpb) {
+      const float* src = partials + ((size_t)b * nchunks * groups + part * gpb + gl) * 2;
+      for (int c = l; c < nchunks; c += tpg) {
+        ts += src[(size_t)c * groups * 2];
+        tq += src[(size_t)c * groups * 2 + 1];
+      }
+    }
+    s_a[tid] = ts;
+    s_b[tid] = tq;
+  }
+  __syncthreads();
+  if (tid < gpb) {
+    const int tpg = 256 / gpb;
+    float ts = 0.f, tq = 0.f;
+    for (int l = 0; l < tpg; ++l) { ts += s_a[tid * tpg + l]; tq += s_b[tid * tpg + l]; }
+    const float inv = 1.0f / ((float)cpg * (float)HW);
+    const float mean = ts * inv;
+    float var = tq * inv - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    s_mean[tid] = mean;
+    s_rstd[tid] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  for (int c = tid; c < nvb * 8; c += 256) {
+    const int g = c / cpg;
+    const int cg = part * nvb * 8 + c;
+    const float a = s_rstd[g] * gamma[cg];
+    s_a[c] = a;
+    s_b[c] = beta[cg] - s_mean[g] * a;
+  }
+  __syncthreads();
+  if (prow >= P) return;
+  const int c0 = (part * nvb + cv) * 8;
+  float a[8], bb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = s_a[cv * 8 + j]; bb[j] = s_b[cv * 8 + j]; }
+  const int pbeg = chunk * ppc;
+  const int pend = min(HW, pbeg + ppc);
+  const f16* xb = x + ((size_t)b * HW) * ldx + c0;
+  f16* yb = y + ((size_t)b * HW) * ldy + c0;
+  for (int pix = pbeg + prow; pix < pend; pix += P) {
+    const f16x8 v = *reinterpret_cast<const f16x8*>(xb + (size_t)pix * ldx);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = (float)v[j] * a[j] + bb[j];
+      if (with_silu) f = silu_f(f);
+      o[j] = (f16)f;
+    }
+    *reinterpret_cast<f16x8*>(yb + (size_t)pix * ldy) = o;
+  }
+}
+
+int groupnorm_nhwc(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const float* beta, int B, int HW, int C,
+                   int groups, float eps, int with_silu, float* partials, hipStream_t stream) {
+  SDEO_CHECK(y && x && gamma && beta && partials, "groupnorm: null operand");
+  SDEO_CHECK(B > 0 && HW > 0 && C > 0, "groupnorm: empty tensor");
+  SDEO_CHECK(groups > 0 && groups <= 64 && C % groups == 0, "groupnorm: C=%d not divisible into %d groups", C, groups);
+  SDEO_CHECK(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "groupnorm: C=%d ldx=%d ldy=%d must be multiples of 8", C, ldx, ldy);
+  const int nvb = gn_vec_per_block(C, groups);
+  SDEO_CHECK(nvb > 0, "groupnorm: unsupported channel split C=%d groups=%d", C, groups);
+  const int cpg = C / groups;
+  const int parts = (C / 8) / nvb;
+  const int chunks = gn_chunks(HW);
+  const int ppc = cdiv(HW, chunks);
+  dim3 grid(chunks, parts, B);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, stream, x, ldx, HW, C, cpg, nvb, partials, chunks, groups, ppc);
+  hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, stream, y, ldy, x, ldx, gamma, beta, HW, C, cpg, nvb, partials,
+                     chunks, groups, eps, with_silu, ppc);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (`attention.py:372-374`, nn.LayerNorm eps 1e-5): one wave per row, the row lives in
+// registers (<= 4 vectors of 8 per lane => C <= 2048), exact two-pass mean / variance in fp32.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_kernel(f16* __restrict__ y, int ldy, const f16* __restrict__ x, int ldx,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nvec = C / 8;
+  f16x8 v[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int vi = lane + i * 64;
+    if (vi < nvec) {
+      v[i] = *reinterpret_cast<const f16x8*>(x + (size_t)row * ldx + vi * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)v[i][j];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int vi = lane + i * 64;
+    if (vi < nvec) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = (float)v[i][j] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int vi = lane + i * 64;
+    if (vi < nvec) {
+      f16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        o[j] = (f16)(((float)v[i][j] - mean) * rstd * gamma[vi * 8 + j] + beta[vi * 8 + j]);
+      *reinterpret_cast<f16x8*>(y + (size_t)row * ldy + vi * 8) = o;
+    }
+  }
+}
+
+int layernorm(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const float* beta, int rows, int C, float eps,
+              hipStream_t stream) {
+  SDEO_CHECK(y && x && gamma && beta, "layernorm: null operand");
+  SDEO_CHECK(rows > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "layernorm: rows=%d C=%d ldx=%d ldy=%d", rows, C,
+             ldx, ldy);
+  SDEO_CHECK(C <= 2048, "layernorm: C=%d > 2048 unsupported", C);
+  const int vpl = cdiv(C / 8, 64);
+  dim3 grid(cdiv(rows, 4));
+  if (vpl <= 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, stream, y, ldy, x, ldx, gamma, beta, rows, C, eps);
+  else if (vpl == 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, stream, y, ldy, x, ldx, gamma, beta, rows, C, eps);
+  else hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, stream, y, ldy, x, ldx, gamma, beta, rows, C, eps);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// row softmax of fp32 scores (VAE AttnBlock, `model.py:186-193`): one 256-thread block per row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(f16* __restrict__ p, int ldp, const float* __restrict__ s, int lds,
+                                                           int cols, float scale) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float* src = s + (size_t)row * lds;
+  float mx = -INFINITY;
+  for (int c = tid; c < cols; c += 256) mx = fmaxf(mx, src[c] * scale);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int c = tid; c < cols; c += 256) sum += __expf(src[c] * scale - mx);
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  sum = red[0] + red[1] + red[2] + red[3];
+  const float inv = 1.0f / sum;
+  for (int c = tid; c < cols; c += 256) p[(size_t)row * ldp + c] = (f16)(__expf(src[c] * scale - mx) * inv);
+}
+
+int softmax_rows(f16* p, int ldp, const float* s, int lds, int rows, int cols, float scale, hipStream_t stream) {
+  SDEO_CHECK(p && s && rows > 0 && cols > 0, "softmax_rows: bad operand");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, p, ldp, s, lds, cols, scale);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace sdeo

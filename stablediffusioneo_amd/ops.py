@@ -1,0 +1,162 @@
+"""Op-level Python wrappers over the C ABI (include/sdeo.h).  torch is used only to own device
+memory and the current HIP stream; every computation happens inside libsdeo.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, cur_stream, ptr
+
+_f = C.c_float
+_i = C.c_int
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.SdeoError("HIP ops need device tensors (no CPU fallback)")
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def groupnorm_nhwc(x, gamma, beta, groups=32, eps=1e-5, swish=False):
+    """x: (N,H,W,C) fp16 contiguous; gamma/beta fp32 (C,)."""
+    lib = _lib.load()
+    _need_cuda(x, gamma, beta)
+    n, h, w, c = x.shape
+    assert x.dtype == torch.float16 and x.is_contiguous()
+    y = torch.empty_like(x)
+    ws = _ws(lib.sdeo_groupnorm_workspace_bytes(_i(n), _i(h * w), _i(groups)), x.device)
+    check(lib.sdeo_groupnorm_nhwc_f16(ptr(y), ptr(x), ptr(gamma), ptr(beta), _i(n), _i(h), _i(w), _i(c), _i(groups),
+                                      _f(eps), _i(int(swish)), ptr(ws), cur_stream()), "groupnorm")
+    return y
+
+
+def krsc_from_oihw(w_oihw_f32, cin_pad=None):
+    """fp32 OIHW (device) -> fp16 [O][R][S][Ipad]."""
+    lib = _lib.load()
+    _need_cuda(w_oihw_f32)
+    o, i, r, s = w_oihw_f32.shape
+    ip = cin_pad or ((i + 7) // 8) * 8
+    y = torch.empty((o, r, s, ip), dtype=torch.float16, device=w_oihw_f32.device)
+    check(lib.sdeo_oihw_f32_to_krsc_f16(ptr(y), ptr(w_oihw_f32.contiguous()), _i(o), _i(i), _i(r), _i(s), _i(ip),
+                                        cur_stream()), "krsc")
+    return y
+
+
+def conv2d_nhwc(x, w_krsc, bias=None, bias2=None, res=None, stride=1, upsample2x=False, act=0, scale=1.0):
+    """x (N,H,W,Cin) fp16; w_krsc (Cout,k,k,Cin) fp16; returns (N,Ho,Wo,Cout) fp16."""
+    lib = _lib.load()
+    _need_cuda(x, w_krsc)
+    n, h, w, cin = x.shape
+    cout, k, _, cin_w = w_krsc.shape
+    assert cin == cin_w and x.is_contiguous() and w_krsc.is_contiguous()
+    hv, wv = (2 * h, 2 * w) if upsample2x else (h, w)
+    pad = k // 2
+    ho = (hv + 2 * pad - k) // stride + 1
+    wo = (wv + 2 * pad - k) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float16, device=x.device)
+    args = (_i(n), _i(h), _i(w), _i(cin), _i(cout), _i(k), _i(stride), _i(int(upsample2x)))
+    nb = lib.sdeo_conv2d_workspace_bytes(*args)
+    ws = _ws(nb, x.device)
+    check(lib.sdeo_conv2d_nhwc_f16(ptr(y), ptr(x), ptr(w_krsc), ptr(bias), ptr(bias2), ptr(res), *args, _i(act), _f(scale),
+                                   ptr(ws), C.c_size_t(ws.numel()), cur_stream()), "conv2d")
+    return y
+
+
+def gemm(x, w, bias=None, res=None, act=0, scale=1.0, out_f32=False, bias_per_row=False):
+    """y[m][n] = x[m][k] . w[n][k]^T (+bias)(+res); x, w fp16 row-major (may be strided views with unit inner stride)."""
+    lib = _lib.load()
+    _need_cuda(x, w)
+    m, k = x.shape
+    n, k2 = w.shape
+    assert k == k2 and x.stride(1) == 1 and w.stride(1) == 1
+    y = torch.empty((m, n), dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
+    nb = lib.sdeo_gemm_workspace_bytes(_i(m), _i(n), _i(k))
+    ws = _ws(nb, x.device)
+    check(lib.sdeo_gemm_f16(ptr(y), _i(n), ptr(x), _i(x.stride(0)), ptr(w), _i(w.stride(0)), ptr(bias), ptr(res),
+                            _i(res.stride(0) if res is not None else 0), _i(m), _i(n), _i(k), _i(act), _f(scale),
+                            _i(int(out_f32)), _i(int(bias_per_row)), ptr(ws), C.c_size_t(ws.numel()), cur_stream()), "gemm")
+    return y
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    lib = _lib.load()
+    _need_cuda(x, gamma, beta)
+    rows, c = x.shape
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    check(lib.sdeo_layernorm_f16(ptr(y), ptr(x), ptr(gamma), ptr(beta), _i(rows), _i(c), _f(eps), cur_stream()), "layernorm")
+    return y
+
+
+def attention(q, k, vt, heads, tk=None, scale=None):
+    """q (B,Tq,H*d), k (B,TkS,H*d), vt (H*d, B*TkS) fp16 -> (B,Tq,H*d)."""
+    lib = _lib.load()
+    _need_cuda(q, k, vt)
+    b, tq, c = q.shape
+    tks = k.shape[1]
+    tk = tks if tk is None else tk
+    d = c // heads
+    scale = d ** -0.5 if scale is None else scale
+    assert q.is_contiguous() and k.is_contiguous() and vt.is_contiguous() and vt.shape == (c, b * tks)
+    o = torch.empty_like(q)
+    check(lib.sdeo_attention_f16(ptr(o), _i(c), ptr(q), _i(c), ptr(k), _i(k.shape[2]), ptr(vt), _i(b * tks), _i(b), _i(heads),
+                                 _i(tq), _i(tk), _i(tks), _i(d), _f(scale), cur_stream()), "attention")
+    return o
+
+
+def geglu(a):
+    lib = _lib.load()
+    _need_cuda(a)
+    rows, c2 = a.shape
+    y = torch.empty((rows, c2 // 2), dtype=torch.float16, device=a.device)
+    check(lib.sdeo_geglu_f16(ptr(y), ptr(a), _i(rows), _i(c2 // 2), cur_stream()), "geglu")
+    return y
+
+
+def timestep_embedding(t, dim):
+    lib = _lib.load()
+    _need_cuda(t)
+    assert t.dtype == torch.int64
+    out = torch.empty((t.shape[0], dim), dtype=torch.float16, device=t.device)
+    check(lib.sdeo_timestep_embedding_f16(ptr(out), ptr(t), _i(t.shape[0]), _i(dim), cur_stream()), "timestep_embedding")
+    return out
+
+
+def cfg_ddim_step(x, eps_c, eps_u, cfg_scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, noise=None, want_pred_x0=True):
+    lib = _lib.load()
+    _need_cuda(x, eps_c)
+    assert x.dtype == torch.float32 and x.is_contiguous() and eps_c.is_contiguous()
+    x_prev = torch.empty_like(x)
+    p0 = torch.empty_like(x) if want_pred_x0 else None
+    check(lib.sdeo_cfg_ddim_step(ptr(x_prev), ptr(p0), ptr(x), ptr(eps_c), ptr(eps_u), ptr(noise), _f(cfg_scale), _f(a_t),
+                                 _f(a_prev), _f(sigma_t), _f(sqrt_one_minus_at), C.c_int64(x.numel()), cur_stream()),
+          "cfg_ddim_step")
+    return x_prev, p0
+
+
+def nchw_to_nhwc_f16(x, c_pad=None):
+    lib = _lib.load()
+    _need_cuda(x)
+    n, c, h, w = x.shape
+    cp = c_pad or c
+    y = torch.empty((n, h, w, cp), dtype=torch.float16, device=x.device)
+    check(lib.sdeo_nchw_f32_to_nhwc_f16(ptr(y), _i(cp), ptr(x.contiguous().float()), _i(n), _i(c), _i(h * w), cur_stream()),
+          "nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw_f32(x, c=None, scale=1.0):
+    lib = _lib.load()
+    _need_cuda(x)
+    n, h, w, ld = x.shape
+    c = c or ld
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    check(lib.sdeo_nhwc_f16_to_nchw_f32(ptr(y), ptr(x), _i(ld), _i(n), _i(c), _i(h * w), _f(scale), cur_stream()),
+          "nhwc_to_nchw")
+    return y

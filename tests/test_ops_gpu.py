@@ -1,0 +1,278 @@
+"""GPU parity of every hand-written kernel, called through the C ABI (ctypes -> libsdeo.so).
+
+Reference for each op = the same arithmetic in PyTorch fp32 on the CPU, evaluated on the fp16-rounded
+inputs the kernel sees (plus the reference-module goldens in tests/golden/blocks.npz where they exist).
+Tolerances are for fp16 storage with fp32 accumulation: |err| <= atol + rtol*|ref| with rtol 2e-3
+(fp16 has 2^-11 = 4.9e-4 relative rounding) unless a test states otherwise."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.common import GOLDEN, randn
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from stablediffusioneo_amd import ops as _ops
+    return _ops
+
+
+def h16(t):
+    return t.to(torch.float16)
+
+
+def assert_close(got, ref, rtol=2e-3, atol=2e-3, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    bad = err > bound
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} out of tolerance, max err {float(err.max()):.4g} " \
+                          f"(ref max {float(ref.abs().max()):.4g})"
+
+
+# ------------------------------------------------------------------ GroupNorm
+
+GN_SHAPES = [  # (N, C, H, W): every (C, level) of SURVEY.md App. A that matters + VAE + odd sizes
+    (2, 320, 64, 64), (2, 640, 32, 32), (2, 960, 32, 32), (2, 1280, 16, 16), (2, 1920, 16, 16), (2, 2560, 8, 8),
+    (2, 1280, 8, 8), (2, 640, 64, 64), (1, 128, 96, 80), (1, 256, 40, 24), (1, 512, 16, 16), (2, 64, 5, 7), (3, 96, 6, 10),
+]
+
+
+@pytest.mark.parametrize("shape", GN_SHAPES)
+@pytest.mark.parametrize("eps,swish", [(1e-5, True), (1e-6, False)])
+def test_groupnorm(ops, shape, eps, swish):
+    n, c, h, w = shape
+    x = h16(randn(shape, 100 + c) * 1.7 + 0.3)
+    gamma = 1.0 + 0.1 * randn((c,), 101)
+    beta = 0.05 * randn((c,), 102)
+    ref = F.group_norm(x.float(), 32, gamma, beta, eps)
+    if swish:
+        ref = F.silu(ref)
+    y = ops.groupnorm_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), gamma.to(DEV), beta.to(DEV), 32, eps, swish)
+    assert_close(y.permute(0, 3, 1, 2), ref, what=f"groupnorm {shape}")
+
+
+def test_groupnorm_golden(ops):
+    """against the reference modules' own outputs (GroupNorm32 eps 1e-5; Normalize eps 1e-6 + SiLU)"""
+    from stablediffusioneo_amd import spec as S
+    g = np.load(os.path.join(GOLDEN, "blocks.npz"))
+    x = randn((2, 96, 6, 10), 19) * 3.0 + 0.5
+    w = S.synth_tensor("gn.weight.norm", (96,), 1)
+    b = S.synth_tensor("gn.bias", (96,), 1)
+    xd = h16(x).permute(0, 2, 3, 1).contiguous().to(DEV)
+    y5 = ops.groupnorm_nhwc(xd, w.to(DEV), b.to(DEV), 32, 1e-5, False).permute(0, 3, 1, 2)
+    y6 = ops.groupnorm_nhwc(xd, w.to(DEV), b.to(DEV), 32, 1e-6, True).permute(0, 3, 1, 2)
+    # inputs are rounded to fp16 here, so allow that rounding through the normalisation (|x| up to ~12)
+    assert_close(y5, torch.tensor(g["gn_eps5"]), rtol=4e-3, atol=6e-3, what="gn golden eps5")
+    assert_close(y6, torch.tensor(g["gn_eps6_silu"]), rtol=4e-3, atol=6e-3, what="gn golden eps6+silu")
+
+
+def test_groupnorm_deterministic(ops):
+    x = h16(randn((2, 320, 32, 32), 7)).permute(0, 2, 3, 1).contiguous().to(DEV)
+    g = torch.ones(320, device=DEV)
+    b = torch.zeros(320, device=DEV)
+    y1 = ops.groupnorm_nhwc(x, g, b, 32, 1e-5, True)
+    y2 = ops.groupnorm_nhwc(x, g, b, 32, 1e-5, True)
+    assert torch.equal(y1, y2)
+
+
+def test_groupnorm_rejects_bad_shape(ops):
+    from stablediffusioneo_amd._lib import SdeoError
+    x = torch.zeros((1, 4, 4, 36), dtype=torch.float16, device=DEV)
+    with pytest.raises(SdeoError):
+        ops.groupnorm_nhwc(x, torch.ones(36, device=DEV), torch.zeros(36, device=DEV), 32)
+
+
+# ------------------------------------------------------------------ conv2d (implicit GEMM)
+
+CONV_CASES = [  # (N, Cin, H, W, Cout, k, stride, ups)
+    (2, 320, 32, 32, 320, 3, 1, 0),      # fast path, 128x64 / 64x64 tiles
+    (2, 640, 16, 16, 1280, 3, 1, 0),     # split-K candidate
+    (2, 1280, 8, 8, 1280, 3, 1, 0),      # M=128: split-K
+    (2, 320, 32, 32, 320, 3, 2, 0),      # Downsample
+    (2, 640, 16, 16, 640, 3, 1, 1),      # Upsample folded
+    (2, 960, 16, 16, 320, 1, 1, 0),      # skip_connection 1x1
+    (2, 8, 24, 40, 320, 3, 1, 0),        # conv_in (Cin padded 4->8), generic path
+    (2, 16, 32, 48, 32, 3, 2, 0),        # hint block
+    (2, 96, 16, 24, 96, 3, 1, 0),        # hint block, Cin=96 generic
+    (1, 320, 24, 40, 4, 3, 1, 0),        # out conv, N=4
+    (1, 128, 40, 56, 128, 3, 1, 0),      # VAE
+    (3, 64, 7, 9, 64, 3, 1, 0),          # ragged M
+    (1, 192, 5, 5, 72, 3, 2, 0),         # ragged everything
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(ops, case):
+    n, cin, h, w, cout, k, stride, ups = case
+    x = h16(randn((n, cin, h, w), 200 + cin))
+    wt = h16(randn((cout, cin, k, k), 201) * (1.0 / (cin * k * k)) ** 0.5)
+    bias = 0.1 * randn((cout,), 202)
+    xin = F.interpolate(x.float(), scale_factor=2, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, wt.float(), bias, stride=stride, padding=k // 2)
+    wk = wt.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), wk, bias.to(DEV), stride=stride, upsample2x=bool(ups))
+    assert_close(y.permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3, what=f"conv {case}")
+
+
+def test_conv2d_epilogue(ops):
+    """bias + per-image time-embedding add + SiLU + scale + residual in one launch"""
+    n, cin, h, w, cout = 2, 128, 12, 20, 64
+    x = h16(randn((n, cin, h, w), 210))
+    wt = h16(randn((cout, cin, 3, 3), 211) * (1.0 / (cin * 9)) ** 0.5)
+    bias = 0.1 * randn((cout,), 212)
+    bias2 = 0.3 * randn((n, cout), 213)
+    res = h16(randn((n, cout, h, w), 214))
+    ref = F.silu(F.conv2d(x.float(), wt.float(), bias, padding=1) + bias2[:, :, None, None]) * 0.825 + res.float()
+    y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), wt.permute(0, 2, 3, 1).contiguous().to(DEV), bias.to(DEV),
+                        bias2.to(DEV), res.permute(0, 2, 3, 1).contiguous().to(DEV), act=1, scale=0.825)
+    assert_close(y.permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3, what="conv epilogue")
+
+
+def test_krsc_transform(ops):
+    w = randn((24, 4, 3, 3), 220)
+    y = ops.krsc_from_oihw(w.to(DEV), 8).cpu()
+    assert y.shape == (24, 3, 3, 8)
+    assert torch.equal(y[..., :4], w.permute(0, 2, 3, 1).half())
+    assert float(y[..., 4:].abs().max()) == 0.0
+
+
+def test_conv2d_rejects_bad_channels(ops):
+    from stablediffusioneo_amd._lib import SdeoError
+    x = torch.zeros((1, 4, 4, 12), dtype=torch.float16, device=DEV)
+    w = torch.zeros((8, 3, 3, 12), dtype=torch.float16, device=DEV)
+    with pytest.raises(SdeoError):
+        ops.conv2d_nhwc(x, w)
+
+
+# ------------------------------------------------------------------ GEMM
+
+GEMM_CASES = [(8192, 320, 320), (2048, 5120, 640), (512, 1280, 5120), (154, 640, 768), (2, 1280, 320), (2, 1280, 1280),
+              (128, 10240, 1280), (77, 72, 96), (1000, 36, 200)]
+
+
+@pytest.mark.parametrize("m,n,k", GEMM_CASES)
+def test_gemm(ops, m, n, k):
+    x = h16(randn((m, k), 300 + k))
+    w = h16(randn((n, k), 301) * (1.0 / k) ** 0.5)
+    bias = 0.1 * randn((n,), 302)
+    res = h16(randn((m, n), 303))
+    ref = F.linear(x.float(), w.float(), bias) + res.float()
+    y = ops.gemm(x.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV))
+    assert_close(y, ref, rtol=2e-3, atol=3e-3, what=f"gemm {m}x{n}x{k}")
+
+
+def test_gemm_f32_out_bias_per_row(ops):
+    m, n, k = 64, 200, 128
+    x = h16(randn((m, k), 310))
+    w = h16(randn((n, k), 311) * (1.0 / k) ** 0.5)
+    bias = randn((m,), 312)
+    ref = x.float() @ w.float().t() + bias[:, None]
+    y = ops.gemm(x.to(DEV), w.to(DEV), bias.to(DEV), out_f32=True, bias_per_row=True)
+    assert y.dtype == torch.float32
+    assert_close(y, ref, rtol=1e-4, atol=1e-4, what="gemm f32 out")
+
+
+# ------------------------------------------------------------------ LayerNorm / GEGLU / timestep embedding
+
+@pytest.mark.parametrize("rows,c", [(8192, 320), (2048, 640), (512, 1280), (130, 64), (77, 96), (5, 2048)])
+def test_layernorm(ops, rows, c):
+    x = h16(randn((rows, c), 400 + c) * 2.0 + 0.7)
+    g = 1.0 + 0.1 * randn((c,), 401)
+    b = 0.05 * randn((c,), 402)
+    ref = F.layer_norm(x.float(), (c,), g, b, 1e-5)
+    y = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV))
+    assert_close(y, ref, what=f"layernorm {rows}x{c}")
+
+
+@pytest.mark.parametrize("rows,c", [(8192, 1280), (512, 5120), (33, 256)])
+def test_geglu(ops, rows, c):
+    a = h16(randn((rows, 2 * c), 410) * 1.5)
+    xa, gate = a.float().chunk(2, dim=-1)
+    ref = xa * F.gelu(gate)
+    assert_close(ops.geglu(a.to(DEV)), ref, what="geglu")
+
+
+def test_timestep_embedding(ops):
+    g = np.load(os.path.join(GOLDEN, "blocks.npz"))
+    t = torch.tensor([1, 51, 501, 951, 981], dtype=torch.long)
+    y = ops.timestep_embedding(t.to(DEV), 320)
+    # fp16 storage of values in [-1,1]; arguments up to 981 rad evaluated in fp32
+    assert_close(y, torch.tensor(g["timestep_embedding_320"]), rtol=0, atol=1.5e-3, what="timestep embedding")
+
+
+# ------------------------------------------------------------------ attention
+
+ATTN_CASES = [  # (B, heads, Tq, Tk, d)
+    (2, 8, 1024, 1024, 40), (2, 8, 256, 256, 80), (2, 8, 256, 256, 160), (2, 8, 64, 64, 160),
+    (2, 8, 1024, 77, 40), (2, 8, 256, 77, 80), (2, 8, 64, 77, 160),
+    (2, 4, 128, 128, 16), (2, 4, 200, 77, 32), (1, 4, 100, 100, 64), (2, 8, 70, 70, 8),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention(ops, case):
+    b, hds, tq, tk, d = case
+    c = hds * d
+    tks = ((tk + 7) // 8) * 8
+    q = h16(randn((b, tq, c), 500 + d))
+    k = torch.zeros((b, tks, c), dtype=torch.float16)
+    v = torch.zeros((b, tks, c), dtype=torch.float16)
+    k[:, :tk] = h16(randn((b, tk, c), 501))
+    v[:, :tk] = h16(randn((b, tk, c), 502))
+    sp = lambda t, T: t.float().reshape(b, T, hds, d).permute(0, 2, 1, 3)
+    sim = torch.einsum("bhid,bhjd->bhij", sp(q, tq), sp(k[:, :tk], tk)) * d ** -0.5
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(v[:, :tk], tk)).permute(0, 2, 1, 3).reshape(b, tq, c)
+    vt = v.reshape(b * tks, c).t().contiguous()
+    o = ops.attention(q.to(DEV), k.to(DEV), vt.to(DEV), hds, tk=tk)
+    # P is rounded to fp16 before P.V (rel 4.9e-4 per term), output stored in fp16
+    assert_close(o, ref, rtol=3e-3, atol=3e-3, what=f"attention {case}")
+
+
+def test_attention_spike(ops):
+    """force the online-softmax rescale: one key dominates late in the sequence"""
+    b, hds, t, d = 1, 4, 256, 32
+    c = hds * d
+    q = h16(randn((b, t, c), 510))
+    k = h16(randn((b, t, c), 511))
+    v = h16(randn((b, t, c), 512))
+    k[:, 200] = q[:, 5] * 4.0
+    sp = lambda x: x.float().reshape(b, t, hds, d).permute(0, 2, 1, 3)
+    sim = torch.einsum("bhid,bhjd->bhij", sp(q), sp(k)) * d ** -0.5
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(v)).permute(0, 2, 1, 3).reshape(b, t, c)
+    vt = v.reshape(b * t, c).t().contiguous()
+    o = ops.attention(q.to(DEV), k.to(DEV), vt.to(DEV), hds)
+    assert_close(o, ref, rtol=3e-3, atol=3e-3, what="attention spike")
+
+
+# ------------------------------------------------------------------ sampler step / layout
+
+def test_cfg_ddim_step(ops):
+    from oracle import sd_oracle as O
+    x = randn((2, 4, 16, 16), 600)
+    ec = randn((2, 4, 16, 16), 601)
+    eu = randn((2, 4, 16, 16), 602)
+    a_t, a_prev, sig = 0.0365, 0.11, 0.0
+    e = eu + 9.0 * (ec - eu)
+    xr, pr = O.ddim_step(x, e, a_t, a_prev, sig, (1 - a_t) ** 0.5)
+    xp, p0 = ops.cfg_ddim_step(x.to(DEV), ec.to(DEV), eu.to(DEV), 9.0, a_t, a_prev, sig, (1 - a_t) ** 0.5)
+    assert_close(xp, xr, rtol=1e-5, atol=1e-5, what="x_prev")
+    assert_close(p0, pr, rtol=1e-5, atol=1e-4, what="pred_x0")
+
+
+def test_layout_roundtrip(ops):
+    x = randn((2, 4, 6, 10), 610)
+    y = ops.nchw_to_nhwc_f16(x.to(DEV), 8)
+    assert y.shape == (2, 6, 10, 8) and float(y[..., 4:].abs().max()) == 0.0
+    z = ops.nhwc_to_nchw_f32(y, 4)
+    assert torch.equal(z.cpu(), x.half().float())
