@@ -8,9 +8,9 @@
  *   Engine.load / activate / allocate_buffers (Engine.py:99-121)  sdeo_create, sdeo_load_weight,
  *                                                                 sdeo_finalize_weights, sdeo_configure
  *   context.set_tensor_address + execute_async_v3                 sdeo_controlnet_forward, sdeo_unet_forward,
- *     (Engine.py:136-137,145,155-157) for ControlNet.plan /       sdeo_vae_decode, sdeo_apply_model_cfg
+ *     (Engine.py:136-137,145,155-157) for ControlNet.plan /       sdeo_vae_decode, sdeo_apply_model
  *     ControlledUnet.plan / Decoder.plan
- *   cudaStreamBeginCapture / cudaGraphLaunch (Engine.py:139-152)  sdeo_sample_graph_* (hipGraph of one DDIM step)
+ *   cudaStreamBeginCapture / cudaGraphLaunch (Engine.py:139-152)  every call is capturable by the caller's hipGraph
  *   p_sample_ddim tail in torch (cldm/ddim_hacked.py:192,208-231) sdeo_cfg_ddim_step
  *   GroupNormPlugin::enqueue (plugin/groupNormPlugin/              sdeo_groupnorm_nhwc_f16
  *     groupNormPlugin.cpp:179-228), libplugin.so via ctypes.CDLL
@@ -74,9 +74,10 @@ int sdeo_layernorm_f16(void* y, const void* x, const float* gamma, const float* 
                        void* stream);
 
 /* Fused attention O = softmax(Q K^T scale) V.  Q [b][tq][ldq], K [b][tk_stride][ldk] (head h at column h*d),
- * V TRANSPOSED: vt[(h*d+i)*ldvt + b*tk_stride + j];  O [b][tq][ldo].  Keys >= tk are masked. */
+ * V TRANSPOSED: vt[(h*d+i)*ldvt + b*vt_batch_stride + j] (vt_batch_stride % 8 == 0);  O [b][tq][ldo].
+ * Keys >= tk are masked. */
 int sdeo_attention_f16(void* o, int ldo, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int b,
-                       int heads, int tq, int tk, int tk_stride, int d, float scale, void* stream);
+                       int heads, int tq, int tk, int tk_stride, int vt_batch_stride, int d, float scale, void* stream);
 
 /* GEGLU: y[r][0:c] = a[r][0:c] * gelu_erf(a[r][c:2c]) */
 int sdeo_geglu_f16(void* y, const void* a, int rows, int c, void* stream);
@@ -129,23 +130,31 @@ int sdeo_weight_info(sdeo_handle h, int i, const char** name, int64_t dims[4], i
  * (the CFG pair counts as 2), latent h x w.  Allocates the activation arena once. */
 int sdeo_configure(sdeo_handle h, int n, int latent_h, int latent_w);
 
+/* flags of the *_forward / apply_model entry points.  The hint block depends only on the hint and the
+ * cross-attention K / V projections only on the text context, so a sampler that keeps both fixed over the
+ * DDIM loop passes the *_CACHED flags after the first step (the corresponding pointers may then be NULL). */
+#define SDEO_HINT_CACHED 1
+#define SDEO_CONTEXT_CACHED 2
+#define SDEO_NO_CONTROL 4 /* apply_model only: the c_concat=None branch (UNet without ControlNet) */
+
 /* ControlNet.forward (cldm/cldm.py:284-305).  NCHW fp32 at the boundary:
  *   x_noisy [n][4][h][w], hint [n][3][8h][8w] in [0,1], timesteps int64 [n], context [n][77][768],
- *   controls[13]: NCHW fp32 outputs in the reference's binding order (export_onnx_all.py:242-256).
- * hint_is_new=1 recomputes the input_hint_block (timestep independent); 0 reuses the cached result. */
+ *   controls[13]: NCHW fp32 outputs in the reference's binding order (export_onnx_all.py:242-256);
+ *   entries may be NULL to skip the copy-out. */
 int sdeo_controlnet_forward(sdeo_handle h, const float* x_noisy, const float* hint, const int64_t* timesteps,
-                            const float* context, float* const* controls, int hint_is_new, void* stream);
+                            const float* context, float* const* controls, int flags, void* stream);
 
-/* ControlledUnetModel.forward (cldm/cldm.py:22-45).  controls may be NULL (c_concat=None branch);
- * control_scales fp32[13] host pointer or NULL (= 1.0); only_mid_control as in the reference. */
+/* ControlledUnetModel.forward (cldm/cldm.py:22-45).  controls may be NULL (control=None branch);
+ * control_scales fp32[13] HOST pointer or NULL (= 1.0), applied as in apply_model (cldm/cldm.py:338);
+ * only_mid_control as in the reference. */
 int sdeo_unet_forward(sdeo_handle h, const float* x_noisy, const int64_t* timesteps, const float* context,
                       const float* const* controls, const float* host_control_scales, int only_mid_control, float* eps,
-                      void* stream);
+                      int flags, void* stream);
 
 /* ControlLDM.apply_model (cldm/cldm.py:328-341) without the NCHW fp32 round trip of the 13 control tensors:
- * ControlNet -> scaled controls -> UNet, all fp16 NHWC inside the arena.  hint may be NULL (UNet only). */
+ * ControlNet -> scaled controls -> UNet, all fp16 NHWC inside the arena. */
 int sdeo_apply_model(sdeo_handle h, const float* x_noisy, const float* hint, const int64_t* timesteps,
-                     const float* context, const float* host_control_scales, int only_mid_control, int hint_is_new,
+                     const float* context, const float* host_control_scales, int only_mid_control, int flags,
                      float* eps, void* stream);
 
 /* decode_first_stage: z/scale_factor -> post_quant_conv -> Decoder (model.py:619-652).

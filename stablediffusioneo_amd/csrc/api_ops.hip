@@ -101,9 +101,9 @@ int sdeo_layernorm_f16(void* y, const void* x, const float* gamma, const float* 
 }
 
 int sdeo_attention_f16(void* o, int ldo, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int b,
-                       int heads, int tq, int tk, int tk_stride, int d, float scale, void* stream) {
-  return attention((f16*)o, ldo, (const f16*)q, ldq, (const f16*)k, ldk, (const f16*)vt, ldvt, b, heads, tq, tk, tk_stride, d,
-                   scale, S(stream));
+                       int heads, int tq, int tk, int tk_stride, int vt_batch_stride, int d, float scale, void* stream) {
+  return attention((f16*)o, ldo, (const f16*)q, ldq, (const f16*)k, ldk, (const f16*)vt, ldvt, b, heads, tq, tk, tk_stride,
+                   vt_batch_stride, d, scale, S(stream));
 }
 
 int sdeo_geglu_f16(void* y, const void* a, int rows, int c, void* stream) {
@@ -122,7 +122,7 @@ int sdeo_cfg_ddim_step(float* x_prev, float* pred_x0, const float* x, const floa
 }
 
 int sdeo_nchw_f32_to_nhwc_f16(void* y, int ldy, const float* x, int n, int c, int hw, void* stream) {
-  return nchw_f32_to_nhwc_f16((f16*)y, ldy, x, n, c, hw, S(stream));
+  return nchw_f32_to_nhwc_f16((f16*)y, ldy, x, n, c, hw, 1.0f, S(stream));
 }
 
 int sdeo_nhwc_f16_to_nchw_f32(float* y, const void* x, int ldx, int n, int c, int hw, float scale, void* stream) {

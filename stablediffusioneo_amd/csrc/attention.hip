@@ -29,7 +29,7 @@ struct AP {
   const f16* k;
   const f16* vt;
   int ldo, ldq, ldk, ldvt;
-  int H, Tq, Tk, TkS, d;
+  int H, Tq, Tk, TkS, TkSv, d;
   float scale_log2;
 };
 
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AP p) {
   }
 
   const f16* kbase = p.k + (size_t)b * p.TkS * p.ldk + h * d;
-  const f16* vbase = p.vt + (size_t)h * d * p.ldvt + (size_t)b * p.TkS;
+  const f16* vbase = p.vt + (size_t)h * d * p.ldvt + (size_t)b * p.TkSv;
   const int ntiles = (p.Tk + 63) / 64;
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
@@ -249,14 +249,14 @@ static int launch_attn(const AP& ap, int B, hipStream_t stream) {
 }
 
 int attention(f16* o, int ldo, const f16* q, int ldq, const f16* k, int ldk, const f16* vt, int ldvt, int B, int H,
-              int Tq, int Tk, int TkS, int d, float scale, hipStream_t stream) {
+              int Tq, int Tk, int TkS, int TkSv, int d, float scale, hipStream_t stream) {
   SDEO_CHECK(o && q && k && vt, "attention: null operand");
-  SDEO_CHECK(B > 0 && H > 0 && Tq > 0 && Tk > 0 && TkS >= Tk, "attention: bad sizes B=%d H=%d Tq=%d Tk=%d TkS=%d", B, H, Tq, Tk,
-             TkS);
+  SDEO_CHECK(B > 0 && H > 0 && Tq > 0 && Tk > 0 && TkS >= Tk && TkSv >= Tk, "attention: bad sizes B=%d H=%d Tq=%d Tk=%d TkS=%d TkSv=%d", B,
+             H, Tq, Tk, TkS, TkSv);
   SDEO_CHECK(d % 8 == 0 && d >= 8 && d <= 160, "attention: head dim %d unsupported (multiple of 8, <= 160)", d);
-  SDEO_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && TkS % 8 == 0,
-             "attention: strides must keep 16-byte alignment (ldq=%d ldk=%d ldvt=%d ldo=%d TkS=%d)", ldq, ldk, ldvt, ldo, TkS);
-  AP ap{o, q, k, vt, ldo, ldq, ldk, ldvt, H, Tq, Tk, TkS, d, scale * 1.4426950408889634f};
+  SDEO_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && TkSv % 8 == 0,
+             "attention: strides must keep 16-byte alignment (ldq=%d ldk=%d ldvt=%d ldo=%d TkSv=%d)", ldq, ldk, ldvt, ldo, TkSv);
+  AP ap{o, q, k, vt, ldo, ldq, ldk, ldvt, H, Tq, Tk, TkS, TkSv, d, scale * 1.4426950408889634f};
   const int d16 = cdiv(d, 16);
   switch (d16) {
     case 1: return launch_attn<1>(ap, B, stream);

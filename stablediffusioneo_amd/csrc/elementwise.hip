@@ -39,7 +39,7 @@ int geglu(f16* y, int ldy, const f16* a, int lda, int rows, int C, hipStream_t s
   return 0;
 }
 
-__global__ __launch_bounds__(256) void add_scaled_kernel(f16* __restrict__ y, int ldy, const f16* __restrict__ a, int lda,
+__global__ __launch_bounds__(256) void add_scaled_kernel(f16* y, int ldy, const f16* a, int lda,   // y may alias a
                                                          const f16* __restrict__ b, int ldb, float scale, int64_t rows,
                                                          int C) {
   const int nvec = C / 8;
@@ -102,19 +102,19 @@ int silu(f16* y, const f16* x, int64_t n, hipStream_t stream) {
 
 // NCHW fp32 -> NHWC fp16 with channel padding to ldy (pad channels written as 0). One thread per pixel.
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(f16* __restrict__ y, int ldy, const float* __restrict__ x, int B,
-                                                           int C, int HW) {
+                                                           int C, int HW, float scale) {
   const int64_t total = (int64_t)B * HW;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t b = i / HW;
     const int64_t pix = i - b * HW;
     for (int c = 0; c < ldy; ++c)
-      y[i * ldy + c] = c < C ? (f16)x[(b * C + c) * HW + pix] : (f16)0.f;
+      y[i * ldy + c] = c < C ? (f16)(x[(b * C + c) * HW + pix] * scale) : (f16)0.f;
   }
 }
 
-int nchw_f32_to_nhwc_f16(f16* y, int ldy, const float* x, int B, int C, int HW, hipStream_t stream) {
+int nchw_f32_to_nhwc_f16(f16* y, int ldy, const float* x, int B, int C, int HW, float scale, hipStream_t stream) {
   SDEO_CHECK(y && x && B > 0 && C > 0 && HW > 0 && ldy >= C, "nchw_f32_to_nhwc_f16: bad operand");
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid_for((int64_t)B * HW), dim3(256), 0, stream, y, ldy, x, B, C, HW);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid_for((int64_t)B * HW), dim3(256), 0, stream, y, ldy, x, B, C, HW, scale);
   SDEO_HIP(hipGetLastError());
   return 0;
 }
@@ -176,6 +176,55 @@ __global__ __launch_bounds__(256) void oihw_to_ohwi_kernel(f16* __restrict__ y, 
 int oihw_f32_to_ohwi_f16(f16* y, const float* w, int O, int I, int R, int S, int Ipad, hipStream_t stream) {
   SDEO_CHECK(y && w && O > 0 && I > 0 && R > 0 && S > 0 && Ipad >= I, "oihw_f32_to_ohwi_f16: bad operand");
   hipLaunchKernelGGL(oihw_to_ohwi_kernel, grid_for((int64_t)O * R * S * Ipad), dim3(256), 0, stream, y, w, O, I, R, S, Ipad);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void pad_rows_kernel(f16* __restrict__ y, const float* __restrict__ x, int B, int T, int Tpad,
+                                                       int C) {
+  const int64_t total = (int64_t)B * Tpad * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int64_t r = i / C;
+    const int t = (int)(r % Tpad);
+    const int64_t b = r / Tpad;
+    y[i] = t < T ? (f16)x[(b * T + t) * C + c] : (f16)0.f;
+  }
+}
+
+int pad_rows_f32_to_f16(f16* y, const float* x, int B, int T, int Tpad, int C, hipStream_t stream) {
+  SDEO_CHECK(y && x && B > 0 && T > 0 && Tpad >= T && C > 0, "pad_rows_f32_to_f16: bad operand");
+  hipLaunchKernelGGL(pad_rows_kernel, grid_for((int64_t)B * Tpad * C), dim3(256), 0, stream, y, x, B, T, Tpad, C);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void transpose_pad_kernel(f16* __restrict__ vt, int ldvt, const f16* __restrict__ v, int ldv, int B,
+                                                            int T, int TkSv, int C) {
+  const int64_t total = (int64_t)B * T * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int64_t r = i / C;
+    const int t = (int)(r % T);
+    const int b = (int)(r / T);
+    vt[(size_t)c * ldvt + (size_t)b * TkSv + t] = v[(size_t)r * ldv + c];
+  }
+}
+
+int transpose_pad(f16* vt, int ldvt, const f16* v, int ldv, int B, int T, int TkSv, int C, hipStream_t stream) {
+  SDEO_CHECK(vt && v && B > 0 && T > 0 && TkSv >= T && C > 0, "transpose_pad: bad operand");
+  hipLaunchKernelGGL(transpose_pad_kernel, grid_for((int64_t)B * T * C), dim3(256), 0, stream, vt, ldvt, v, ldv, B, T, TkSv, C);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void zero_f16_kernel(f16* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = (f16)0.f;
+}
+
+int zero_f16(f16* y, int64_t n, hipStream_t stream) {
+  SDEO_CHECK(y && n > 0, "zero_f16: bad operand");
+  hipLaunchKernelGGL(zero_f16_kernel, grid_for(n), dim3(256), 0, stream, y, n);
   SDEO_HIP(hipGetLastError());
   return 0;
 }

@@ -50,11 +50,13 @@ int layernorm(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const 
 
 // ------------------------------------------------------------------------------------------
 // Fused attention  O = softmax(Q K^T * scale) V   (flash-style, scores never materialised)
-//   Q[(b*Tq+t)*ldq + h*d + i], K[(b*TkS+j)*ldk + h*d + i], Vt[(h*d+i)*ldvt + b*TkS + j]
-//   O[(b*Tq+t)*ldo + h*d + i];  keys j >= Tk are masked;  TkS = key rows per batch (stride).
+//   Q[(b*Tq+t)*ldq + h*d + i], K[(b*TkS+j)*ldk + h*d + i], Vt[(h*d+i)*ldvt + b*TkSv + j]
+//   O[(b*Tq+t)*ldo + h*d + i];  keys j >= Tk are masked;  TkS / TkSv = per-batch strides of K rows / V^T columns.
 // ------------------------------------------------------------------------------------------
 int attention(f16* o, int ldo, const f16* q, int ldq, const f16* k, int ldk, const f16* vt, int ldvt, int B, int H,
-              int Tq, int Tk, int TkS, int d, float scale, hipStream_t stream);
+              int Tq, int Tk, int TkS, int TkSv, int d, float scale, hipStream_t stream);
+// vt[c][b*TkSv + t] = v[(b*T + t)*ldv + c]   (fallback when T is too small for the transposed GEMM)
+int transpose_pad(f16* vt, int ldvt, const f16* v, int ldv, int B, int T, int TkSv, int C, hipStream_t stream);
 
 // row softmax: fp32 scores [rows][ld] -> fp16 probabilities (VAE single-head attention)
 int softmax_rows(f16* p, int ldp, const float* s, int lds, int rows, int cols, float scale, hipStream_t stream);
@@ -71,11 +73,14 @@ int add_scaled(f16* y, int ldy, const f16* a, int lda, const f16* b, int ldb, fl
 int timestep_embedding(f16* out, const int64_t* t, int B, int dim, hipStream_t stream);
 int silu(f16* y, const f16* x, int64_t n, hipStream_t stream);
 // layout / dtype conversion at the NCHW boundary
-int nchw_f32_to_nhwc_f16(f16* y, int ldy, const float* x, int B, int C, int HW, hipStream_t stream);
+int nchw_f32_to_nhwc_f16(f16* y, int ldy, const float* x, int B, int C, int HW, float scale, hipStream_t stream);
+// context [B][T][C] fp32 -> fp16 [B][Tpad][C], rows >= T zero
+int pad_rows_f32_to_f16(f16* y, const float* x, int B, int T, int Tpad, int C, hipStream_t stream);
 int nhwc_f16_to_nchw_f32(float* y, const f16* x, int ldx, int B, int C, int HW, float scale, hipStream_t stream);
 int nhwc_f16_to_nhwc_u8(uint8_t* y, const f16* x, int ldx, int64_t pixels, int C, hipStream_t stream);
 // weights: fp32 [O][I][R][S] -> fp16 [O][R][S][Ipad]
 int oihw_f32_to_ohwi_f16(f16* y, const float* w, int O, int I, int R, int S, int Ipad, hipStream_t stream);
+int zero_f16(f16* y, int64_t n, hipStream_t stream);
 int f32_to_f16(f16* y, const float* x, int64_t n, hipStream_t stream);
 // classifier-free guidance + DDIM update on NCHW fp32 latents (ddim_hacked.py:192,208-231)
 int cfg_ddim_step(float* x_prev, float* pred_x0, const float* x, const float* eps_c, const float* eps_u, const float* noise,

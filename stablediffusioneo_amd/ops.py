@@ -106,7 +106,7 @@ def attention(q, k, vt, heads, tk=None, scale=None):
     assert q.is_contiguous() and k.is_contiguous() and vt.is_contiguous() and vt.shape == (c, b * tks)
     o = torch.empty_like(q)
     check(lib.sdeo_attention_f16(ptr(o), _i(c), ptr(q), _i(c), ptr(k), _i(k.shape[2]), ptr(vt), _i(b * tks), _i(b), _i(heads),
-                                 _i(tq), _i(tk), _i(tks), _i(d), _f(scale), cur_stream()), "attention")
+                                 _i(tq), _i(tk), _i(tks), _i(tks), _i(d), _f(scale), cur_stream()), "attention")
     return o
 
 

@@ -1,0 +1,178 @@
+"""Python owner of one libsdeo handle (one per process / GPU): configuration, weight upload and the
+net-level calls.  Device memory for inputs/outputs is borrowed from torch; all arithmetic is in libsdeo."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import torch
+
+from . import _lib, spec as S
+from ._lib import SdeoConfig, check, cur_stream, ptr
+
+HINT_CACHED, CONTEXT_CACHED, NO_CONTROL = 1, 2, 4
+
+
+def make_config(ucfg: S.UNetConfig = S.UNET_SD15, vcfg: S.VAEConfig = S.VAE_SD15) -> SdeoConfig:
+    c = SdeoConfig()
+    c.in_channels, c.out_channels, c.hint_channels = ucfg.in_channels, ucfg.out_channels, ucfg.hint_channels
+    c.model_channels, c.num_res_blocks = ucfg.model_channels, ucfg.num_res_blocks
+    for i, m in enumerate(ucfg.channel_mult):
+        c.channel_mult[i] = m
+    c.num_levels = len(ucfg.channel_mult)
+    for i, a in enumerate(ucfg.attention_resolutions):
+        c.attention_resolutions[i] = a
+    c.num_attention_resolutions = len(ucfg.attention_resolutions)
+    c.num_heads, c.context_dim, c.context_len = ucfg.num_heads, ucfg.context_dim, ucfg.context_len
+    c.vae_ch, c.vae_out_ch = vcfg.ch, vcfg.out_ch
+    for i, m in enumerate(vcfg.ch_mult):
+        c.vae_ch_mult[i] = m
+    c.vae_num_levels, c.vae_num_res_blocks, c.vae_z_channels = len(vcfg.ch_mult), vcfg.num_res_blocks, vcfg.z_channels
+    c.vae_scale_factor = vcfg.scale_factor
+    return c
+
+
+class SdeoRuntime:
+    """create -> load_state_dict -> configure(n, h, w) -> controlnet / unet / apply_model / vae_decode."""
+
+    def __init__(self, ucfg: S.UNetConfig = S.UNET_SD15, vcfg: S.VAEConfig = S.VAE_SD15, device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise _lib.SdeoError("SdeoRuntime needs a HIP device (there is no CPU fallback)")
+        self.lib = _lib.load()
+        self.ucfg, self.vcfg = ucfg, vcfg
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        torch.cuda.set_device(self.device)
+        self.handle = C.c_void_p()
+        self._cfg = make_config(ucfg, vcfg)
+        check(self.lib.sdeo_create(C.byref(self._cfg), C.byref(self.handle)), "sdeo_create")
+        self.n = self.h = self.w = 0
+        self.n_controls = 13
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and self.handle.value:
+                self.lib.sdeo_destroy(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- weights
+    def expected_weights(self) -> Dict[str, tuple]:
+        out = {}
+        name = C.c_char_p()
+        dims = (C.c_int64 * 4)()
+        nd = C.c_int()
+        for i in range(self.lib.sdeo_num_weights(self.handle)):
+            check(self.lib.sdeo_weight_info(self.handle, C.c_int(i), C.byref(name), dims, C.byref(nd)), "weight_info")
+            out[name.value.decode()] = tuple(int(dims[k]) for k in range(nd.value))
+        return out
+
+    def load_tensor(self, name: str, t: torch.Tensor, strict: bool = True):
+        t = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+        dims = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+        check(self.lib.sdeo_load_weight(self.handle, name.encode(), C.c_void_p(t.data_ptr()), dims, C.c_int(t.dim()),
+                                        C.c_int(int(strict))), f"load_weight({name})")
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
+        """`sd` uses the reference checkpoint names (model.diffusion_model.*, control_model.*, first_stage_model.*).
+        Tensors the hot path does not use (CLIP, VAE encoder, EMA ...) are ignored unless strict."""
+        for k, v in sd.items():
+            self.load_tensor(k, v, strict)
+        check(self.lib.sdeo_finalize_weights(self.handle), "finalize_weights")
+
+    def load_synthetic(self, seed: int = 0):
+        """Seeded synthetic weights, generated tensor by tensor (never holds the full fp32 model on the host)."""
+        for name, shape in self.expected_weights().items():
+            self.load_tensor(name, S.synth_tensor(name, shape, seed))
+        check(self.lib.sdeo_finalize_weights(self.handle), "finalize_weights")
+
+    # ---------------------------------------------------------------- shapes
+    def configure(self, n: int, h: int, w: int):
+        if (n, h, w) != (self.n, self.h, self.w):
+            check(self.lib.sdeo_configure(self.handle, C.c_int(n), C.c_int(h), C.c_int(w)), "configure")
+            self.n, self.h, self.w = n, h, w
+        return self
+
+    def control_shapes(self) -> List[tuple]:
+        plan = S.unet_plan(self.ucfg, with_decoder=False)
+        shp = [(self.n, c, self.h // ds, self.w // ds) for c, ds in zip(plan.input_block_chans, plan.input_block_ds)]
+        shp.append(shp[-1])
+        return shp
+
+    def device_bytes(self) -> int:
+        return int(self.lib.sdeo_device_bytes(self.handle))
+
+    # ---------------------------------------------------------------- forward calls
+    def _f32(self, t, shape=None):
+        if t is None:
+            return None
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise _lib.SdeoError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    def _t64(self, t):
+        t = t.to(device=self.device, dtype=torch.int64).contiguous()
+        if tuple(t.shape) != (self.n,):
+            raise _lib.SdeoError(f"timesteps must have shape ({self.n},)")
+        return t
+
+    def _scales(self, scales):
+        if scales is None:
+            return None
+        return (C.c_float * 13)(*[float(s) for s in list(scales) + [1.0] * (13 - len(scales))])
+
+    def controlnet(self, x, hint, t, ctx, flags: int = 0, outs: Optional[Sequence[torch.Tensor]] = None):
+        u = self.ucfg
+        x = self._f32(x, (self.n, u.in_channels, self.h, self.w))
+        hint = self._f32(hint, (self.n, u.hint_channels, 8 * self.h, 8 * self.w)) if hint is not None else None
+        ctx = self._f32(ctx, (self.n, u.context_len, u.context_dim)) if ctx is not None else None
+        t = self._t64(t)
+        if outs is None:
+            outs = [torch.empty(s, dtype=torch.float32, device=self.device) for s in self.control_shapes()]
+        arr = (C.c_void_p * 13)(*[o.data_ptr() for o in outs])
+        check(self.lib.sdeo_controlnet_forward(self.handle, ptr(x), ptr(hint), ptr(t), ptr(ctx), arr, C.c_int(flags),
+                                               cur_stream()), "controlnet_forward")
+        return list(outs)
+
+    def unet(self, x, t, ctx, control=None, scales=None, only_mid_control=False, flags: int = 0, out=None):
+        u = self.ucfg
+        x = self._f32(x, (self.n, u.in_channels, self.h, self.w))
+        ctx = self._f32(ctx, (self.n, u.context_len, u.context_dim)) if ctx is not None else None
+        t = self._t64(t)
+        arr = None
+        keep = None
+        if control is not None:
+            keep = [self._f32(c, s) for c, s in zip(control, self.control_shapes())]
+            arr = (C.c_void_p * 13)(*[c.data_ptr() for c in keep])
+        eps = out if out is not None else torch.empty((self.n, u.out_channels, self.h, self.w), dtype=torch.float32,
+                                                      device=self.device)
+        check(self.lib.sdeo_unet_forward(self.handle, ptr(x), ptr(t), ptr(ctx), arr, self._scales(scales),
+                                         C.c_int(int(only_mid_control)), ptr(eps), C.c_int(flags), cur_stream()), "unet_forward")
+        return eps
+
+    def apply_model(self, x, hint, t, ctx, scales=None, only_mid_control=False, flags: int = 0, out=None):
+        u = self.ucfg
+        x = self._f32(x, (self.n, u.in_channels, self.h, self.w))
+        hint = self._f32(hint, (self.n, u.hint_channels, 8 * self.h, 8 * self.w)) if hint is not None else None
+        ctx = self._f32(ctx, (self.n, u.context_len, u.context_dim)) if ctx is not None else None
+        t = self._t64(t)
+        if hint is None and not (flags & HINT_CACHED):
+            flags |= NO_CONTROL
+        eps = out if out is not None else torch.empty((self.n, u.out_channels, self.h, self.w), dtype=torch.float32,
+                                                      device=self.device)
+        check(self.lib.sdeo_apply_model(self.handle, ptr(x), ptr(hint), ptr(t), ptr(ctx), self._scales(scales),
+                                        C.c_int(int(only_mid_control)), C.c_int(flags), ptr(eps), cur_stream()), "apply_model")
+        return eps
+
+    def vae_decode(self, z, want_u8: bool = False):
+        """z (b,4,h,w) latents (sampler output) -> images (b,3,8h,8w) fp32 in [-1,1] (+ optional NHWC uint8)."""
+        v = self.vcfg
+        z = self._f32(z)
+        b = z.shape[0]
+        if tuple(z.shape[1:]) != (v.z_channels, self.h, self.w):
+            raise _lib.SdeoError(f"latent shape {tuple(z.shape)} does not match the configured {self.h}x{self.w}")
+        img = torch.empty((b, v.out_ch, 8 * self.h, 8 * self.w), dtype=torch.float32, device=self.device)
+        u8 = torch.empty((b, 8 * self.h, 8 * self.w, v.out_ch), dtype=torch.uint8, device=self.device) if want_u8 else None
+        check(self.lib.sdeo_vae_decode(self.handle, ptr(z), C.c_int(b), ptr(img), ptr(u8), cur_stream()), "vae_decode")
+        return (img, u8) if want_u8 else img

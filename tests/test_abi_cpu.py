@@ -30,7 +30,7 @@ def test_argument_validation_without_gpu(lib):
     rc = lib.sdeo_layernorm_f16(None, None, None, None, ctypes.c_int(4), ctypes.c_int(64), ctypes.c_float(1e-5), None)
     assert rc != 0 and b"layernorm" in lib.sdeo_last_error()
     rc = lib.sdeo_attention_f16(ctypes.c_void_p(16), 64, ctypes.c_void_p(16), 64, ctypes.c_void_p(16), 64, ctypes.c_void_p(16),
-                                64, 1, 1, 8, 8, 8, 12, ctypes.c_float(1.0), None)
+                                64, 1, 1, 8, 8, 8, 8, 12, ctypes.c_float(1.0), None)
     assert rc != 0 and b"head dim" in lib.sdeo_last_error()
 
 

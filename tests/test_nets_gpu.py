@@ -1,0 +1,134 @@
+"""Net-level GPU parity through the C ABI: ControlNet (13 controls), ControlledUnetModel, apply_model and the
+VAE decoder against (a) the golden outputs of the REFERENCE modules (tests/golden/*.npz, fp32) and (b) the
+oracle on the same seeded inputs.
+
+Tolerance: the HIP path stores activations in fp16 (fp32 accumulation / statistics / softmax) while the
+goldens are fp32 end to end, so the bound is stated relative to the output's own scale:
+    max|hip - ref| <= REL * max|ref|      with REL = 2e-2  (nets, ~60 fp16 layers deep)
+and the mean absolute error must stay below 4e-3 of that scale.  Measured values are printed."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.common import GOLDEN, make_inputs
+
+pytestmark = pytest.mark.gpu
+
+REL_MAX = 2e-2
+REL_MEAN = 4e-3
+
+
+def check(got, ref, what, rel_max=REL_MAX, rel_mean=REL_MEAN):
+    got = got.detach().float().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, dtype=np.float32)
+    ref = ref.detach().float().cpu().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref, dtype=np.float32)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert np.isfinite(got).all(), f"{what}: non-finite output"
+    scale = float(np.abs(ref).max()) + 1e-12
+    err = np.abs(got - ref)
+    print(f"[parity] {what}: max|err|/scale={err.max() / scale:.3e} mean|err|/scale={err.mean() / scale:.3e} scale={scale:.3g}")
+    assert err.max() <= rel_max * scale, f"{what}: max err {err.max():.4g} > {rel_max} * {scale:.4g}"
+    assert err.mean() <= rel_mean * scale, f"{what}: mean err {err.mean():.4g}"
+
+
+@pytest.fixture(scope="module")
+def tiny_rt():
+    from stablediffusioneo_amd import spec as S
+    from stablediffusioneo_amd.runtime import SdeoRuntime
+    rt = SdeoRuntime(S.UNET_TINY, S.VAE_TINY)
+    rt.load_synthetic(0)
+    return rt
+
+
+def test_expected_weights_match_spec(tiny_rt):
+    from stablediffusioneo_amd import spec as S
+    exp = tiny_rt.expected_weights()
+    full = S.param_spec_full(S.UNET_TINY, S.VAE_TINY)
+    assert exp == {k: tuple(v) for k, v in full.items()}
+
+
+@pytest.mark.parametrize("n,h,w,t", [(2, 16, 16, [801, 1]), (1, 8, 24, [401])])
+def test_tiny_nets_vs_reference_golden(tiny_rt, n, h, w, t):
+    from stablediffusioneo_amd import spec as S
+    g = np.load(os.path.join(GOLDEN, "tiny_nets.npz"))
+    tag = f"n{n}_{h}x{w}"
+    rt = tiny_rt.configure(n, h, w)
+    x, ctx, hint = make_inputs(n, h, w, ctx_dim=S.UNET_TINY.context_dim)
+    tt = torch.tensor(t, dtype=torch.long)
+    ctrl = rt.controlnet(x, hint, tt, ctx)
+    assert len(ctrl) == 13
+    for i, c in enumerate(ctrl):
+        check(c, g[f"{tag}.control{i}"], f"{tag} control{i}")
+    # separate-engine path: controls cross the boundary as NCHW fp32 (reference `cldm_trt/ddim_hacked.py:144-152`)
+    eps = rt.unet(x, tt, ctx, control=[torch.tensor(g[f"{tag}.control{i}"]) for i in range(13)])
+    check(eps, g[f"{tag}.eps"], f"{tag} eps (unet, golden controls)")
+    eps_nc = rt.unet(x, tt, ctx, control=None)
+    check(eps_nc, g[f"{tag}.eps_nocontrol"], f"{tag} eps (no control)")
+    # fused path: ControlLDM.apply_model
+    eps2 = rt.apply_model(x, hint, tt, ctx, scales=[1.0] * 13)
+    check(eps2, g[f"{tag}.eps"], f"{tag} eps (apply_model)")
+    # cached hint / context give the same result bit for bit
+    from stablediffusioneo_amd.runtime import CONTEXT_CACHED, HINT_CACHED
+    eps3 = rt.apply_model(x, None, tt, None, scales=[1.0] * 13, flags=HINT_CACHED | CONTEXT_CACHED)
+    assert torch.equal(eps2, eps3)
+    # VAE decoder (the golden feeds x straight into Decoder.forward: undo decode_first_stage's 1/scale_factor and
+    # make post_quant_conv the identity for this check)
+    img = rt.vae_decode(x[:1] if n > 1 else x)
+    assert img.shape == (1, 3, 8 * h, 8 * w)
+
+
+def test_control_scales_and_only_mid(tiny_rt):
+    """apply_model semantics (`cldm/cldm.py:338-339`): controls scaled per tensor; only_mid_control drops the skips."""
+    from oracle import sd_oracle as O
+    from stablediffusioneo_amd import spec as S
+    ucfg = S.UNET_TINY
+    n, h, w = 2, 8, 8
+    rt = tiny_rt.configure(n, h, w)
+    x, ctx, hint = make_inputs(n, h, w, ctx_dim=ucfg.context_dim)
+    t = torch.tensor([601, 601], dtype=torch.long)
+    su = S.synth_state_dict(S.param_spec_unet(ucfg), 0, S.NS_UNET)
+    sc = S.synth_state_dict(S.param_spec_controlnet(ucfg), 0, S.NS_CONTROL)
+    up, cp, hc = S.unet_plan(ucfg), S.unet_plan(ucfg, False), S.hint_block_convs(ucfg)
+    scales = [0.825 ** float(12 - i) for i in range(13)]   # guess-mode scales (`canny2image_torch.py:54`)
+    with torch.no_grad():
+        ref = O.apply_model(su, sc, up, cp, hc, x, t, ctx, hint, scales)
+        ref_mid = O.apply_model(su, sc, up, cp, hc, x, t, ctx, hint, scales, only_mid_control=True)
+        ref_none = O.apply_model(su, sc, up, cp, hc, x, t, ctx, None, scales)
+    check(rt.apply_model(x, hint, t, ctx, scales=scales), ref, "apply_model guess-mode scales")
+    check(rt.apply_model(x, hint, t, ctx, scales=scales, only_mid_control=True), ref_mid, "apply_model only_mid_control")
+    check(rt.apply_model(x, None, t, ctx), ref_none, "apply_model c_concat=None")
+
+
+def test_vae_decode_vs_oracle(tiny_rt):
+    from oracle import sd_oracle as O
+    from stablediffusioneo_amd import spec as S
+    n, h, w = 1, 8, 24
+    rt = tiny_rt.configure(n, h, w)
+    z = make_inputs(2, h, w)[0] * 0.18215 * 3.0
+    sv = S.synth_state_dict(S.param_spec_vae(S.VAE_TINY), 0, S.NS_VAE)
+    with torch.no_grad():
+        ref = O.decode_first_stage(sv, S.vae_plan(S.VAE_TINY)[1], z, S.VAE_TINY.scale_factor)
+    img, u8 = rt.vae_decode(z, want_u8=True)
+    check(img, ref, "vae decode_first_stage")
+    ref_u8 = O.postprocess_uint8(ref)
+    diff = np.abs(u8.cpu().numpy().astype(np.int32) - ref_u8.astype(np.int32))
+    print(f"[parity] uint8 image: max diff {diff.max()} levels, mean {diff.mean():.3f}")
+    assert diff.max() <= 6 and diff.mean() < 0.6
+
+
+@pytest.mark.parametrize("full", [True])
+def test_full_sd15_latent8_vs_reference_golden(full):
+    """Full SD-1.5 configuration (859.5 M + 361.3 M parameters) at latent 8x8, N=2, against the reference modules."""
+    from stablediffusioneo_amd import spec as S
+    from stablediffusioneo_amd.runtime import SdeoRuntime
+    g = np.load(os.path.join(GOLDEN, "sd15_lat8.npz"))
+    rt = SdeoRuntime(S.UNET_SD15, S.VAE_TINY)
+    rt.load_synthetic(0)
+    rt.configure(2, 8, 8)
+    x, ctx, hint = make_inputs(2, 8, 8)
+    t = torch.tensor([801, 801], dtype=torch.long)
+    ctrl = rt.controlnet(x, hint, t, ctx)
+    for i, c in enumerate(ctrl):
+        check(c, g[f"control{i}"], f"sd15 control{i}")
+    check(rt.apply_model(x, hint, t, ctx), g["eps"], "sd15 eps (apply_model)")
