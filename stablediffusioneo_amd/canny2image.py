@@ -1,0 +1,126 @@
+"""The `hackathon` pipeline of `canny2image_torch.py:18-71` / `canny2image_TRT.py:18-92` on the libsdeo path:
+same `initialize()` / `process(...)` signature and semantics (Canny hint -> text conditioning -> DDIM loop with
+classifier-free guidance -> VAE decode -> uint8 HWC images).
+
+Two stages of the reference pipeline are outside this build's scope and are injectable:
+  * the Canny detector (`annotator/canny`, needs cv2): `apply_canny(img, low, high) -> HxW uint8`; when cv2 is
+    importable the same `cv2.Canny` call is used, otherwise a callable must be supplied;
+  * the CLIP text encoder (`FrozenCLIPEmbedder`): `text_encoder(prompts) -> (B,77,768)`; the default is a
+    deterministic synthetic embedding (seeded by the prompt text) so the pipeline is runnable without weights.
+"""
+from __future__ import annotations
+
+import hashlib
+import random
+
+import numpy as np
+import torch
+
+from . import spec as S
+from .cldm.ddim_hacked import DDIMSampler
+from .cldm.model import create_model
+
+save_memory = False     # `config.py:1`
+
+
+def HWC3(x):
+    """`annotator/util.py:9-25`."""
+    assert x.dtype == np.uint8
+    if x.ndim == 2:
+        x = x[:, :, None]
+    H, W, C = x.shape
+    assert C in (1, 3, 4)
+    if C == 3:
+        return x
+    if C == 1:
+        return np.concatenate([x, x, x], axis=2)
+    color = x[:, :, 0:3].astype(np.float32)
+    alpha = x[:, :, 3:4].astype(np.float32) / 255.0
+    return (color * alpha + 255.0 * (1.0 - alpha)).clip(0, 255).astype(np.uint8)
+
+
+def target_size(H, W, resolution):
+    """size rule of `annotator/util.py:28-38` (shorter side -> resolution, both rounded to multiples of 64)."""
+    k = float(resolution) / min(H, W)
+    return int(np.round(H * k / 64.0)) * 64, int(np.round(W * k / 64.0)) * 64
+
+
+def resize_image(input_image, resolution):
+    H, W, _ = input_image.shape
+    Ht, Wt = target_size(H, W, resolution)
+    if (Ht, Wt) == (H, W):
+        return input_image
+    try:
+        import cv2
+        k = float(resolution) / min(H, W)
+        return cv2.resize(input_image, (Wt, Ht), interpolation=cv2.INTER_LANCZOS4 if k > 1 else cv2.INTER_AREA)
+    except ImportError:     # cv2 is not part of this image: area/bicubic resampling through torch
+        t = torch.from_numpy(input_image).permute(2, 0, 1)[None].float()
+        t = torch.nn.functional.interpolate(t, size=(Ht, Wt), mode="area" if Ht < H else "bicubic")
+        return t[0].permute(1, 2, 0).clamp(0, 255).round().to(torch.uint8).numpy()
+
+
+def synthetic_text_encoder(prompts, length=77, dim=768):
+    out = []
+    for p in prompts:
+        g = torch.Generator(device="cpu")
+        g.manual_seed(int.from_bytes(hashlib.sha256(p.encode()).digest()[:7], "little"))
+        out.append(torch.randn((length, dim), generator=g))
+    return torch.stack(out)
+
+
+def _default_canny():
+    try:
+        import cv2
+        return lambda img, low, high: cv2.Canny(img, low, high)     # `annotator/canny/__init__.py:4-6`
+    except ImportError:
+        return None
+
+
+class hackathon():
+
+    def initialize(self, weights="synthetic:0", config="sd15", apply_canny=None, text_encoder=None):
+        self.apply_canny = apply_canny or _default_canny()
+        self.text_encoder = text_encoder or synthetic_text_encoder
+        self.model = create_model(config, cond_stage_model=self.text_encoder)
+        if isinstance(weights, str) and weights.startswith("synthetic"):
+            self.model.rt.load_synthetic(int(weights.split(":")[1]) if ":" in weights else 0)
+        elif isinstance(weights, dict):
+            self.model.load_state_dict(weights)
+        else:
+            from .cldm.model import load_state_dict
+            self.model.load_state_dict(load_state_dict(weights, location="cuda"))
+        self.ddim_sampler = DDIMSampler(self.model)
+        return self
+
+    def process(self, input_image, prompt, a_prompt, n_prompt, num_samples, image_resolution, ddim_steps, guess_mode,
+                strength, scale, seed, eta, low_threshold, high_threshold, x_T=None):
+        with torch.no_grad():
+            img = resize_image(HWC3(input_image), image_resolution)
+            H, W, C = img.shape
+            if self.apply_canny is None:
+                raise RuntimeError("no Canny detector: cv2 is not importable here, pass apply_canny= to initialize()")
+            detected_map = HWC3(self.apply_canny(img, low_threshold, high_threshold))
+            device = self.model.device
+            control = torch.from_numpy(detected_map.copy()).float().to(device) / 255.0
+            control = torch.stack([control for _ in range(num_samples)], dim=0)
+            control = control.permute(0, 3, 1, 2).contiguous()
+            if seed == -1:
+                seed = random.randint(0, 65535)
+            random.seed(seed)
+            np.random.seed(seed)
+            torch.manual_seed(seed)       # pytorch_lightning.seed_everything (`canny2image_torch.py:42`)
+            cond = {"c_concat": [control],
+                    "c_crossattn": [self.model.get_learned_conditioning([prompt + ", " + a_prompt] * num_samples)]}
+            un_cond = {"c_concat": None if guess_mode else [control],
+                       "c_crossattn": [self.model.get_learned_conditioning([n_prompt] * num_samples)]}
+            shape = (4, H // 8, W // 8)
+            # `canny2image_torch.py:54`: guess-mode scales 0.825**(12-i)
+            self.model.control_scales = ([strength * (0.825 ** float(12 - i)) for i in range(13)] if guess_mode
+                                         else ([strength] * 13))
+            samples, intermediates = self.ddim_sampler.sample(ddim_steps, num_samples, shape, cond, verbose=False, eta=eta,
+                                                              unconditional_guidance_scale=scale,
+                                                              unconditional_conditioning=un_cond, x_T=x_T)
+            x_samples = self.model.decode_first_stage_uint8(samples).cpu().numpy()
+            results = [x_samples[i] for i in range(num_samples)]
+        return results

@@ -1,0 +1,58 @@
+"""`cldm/model.py` mirror: create_model / load_state_dict with the reference's signatures.
+
+`create_model(config_path)` in the reference instantiates ControlLDM from `models/cldm_v15.yaml` via OmegaConf
+(`cldm/model.py:24-28`); that YAML is absent from the reference tree and OmegaConf is not needed here: the
+configuration is restated in `stablediffusioneo_amd.spec` (SD-1.5 + ControlNet-1.0).  `config_path` may be that
+YAML (only `model.params.*` keys we know are read, through yaml.safe_load), a config name ("sd15", "tiny") or None.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from .. import spec as S
+from ..runtime import SdeoRuntime
+from .cldm import ControlLDM
+
+
+def get_state_dict(d):
+    return d.get("state_dict", d)
+
+
+def load_state_dict(ckpt_path, location="cpu"):
+    """`cldm/model.py:12-21`: .safetensors or torch checkpoint; returns the flat state dict.
+    Checkpoints are read with loaders that execute nothing from the file (safetensors / weights_only=True)."""
+    _, ext = os.path.splitext(ckpt_path)
+    if ext.lower() == ".safetensors":
+        import safetensors.torch
+        sd = safetensors.torch.load_file(ckpt_path, device="cpu")
+    else:
+        sd = get_state_dict(torch.load(ckpt_path, map_location="cpu", weights_only=True))
+    sd = get_state_dict(sd)
+    print(f"Loaded state_dict from [{ckpt_path}]")
+    return sd
+
+
+_NAMED = {"sd15": (S.UNET_SD15, S.VAE_SD15), "tiny": (S.UNET_TINY, S.VAE_TINY)}
+
+
+def create_model(config_path=None, cond_stage_model=None, device=None):
+    ucfg, vcfg = _NAMED["sd15"]
+    if isinstance(config_path, str) and config_path in _NAMED:
+        ucfg, vcfg = _NAMED[config_path]
+    elif isinstance(config_path, str) and os.path.exists(config_path):
+        import yaml
+        cfg = yaml.safe_load(open(config_path))
+        p = cfg.get("model", {}).get("params", {})
+        u = p.get("unet_config", {}).get("params", {})
+        if u:
+            ucfg = S.UNetConfig(in_channels=u.get("in_channels", 4), out_channels=u.get("out_channels", 4),
+                                model_channels=u.get("model_channels", 320), num_res_blocks=u.get("num_res_blocks", 2),
+                                attention_resolutions=tuple(u.get("attention_resolutions", (4, 2, 1))),
+                                channel_mult=tuple(u.get("channel_mult", (1, 2, 4, 4))), num_heads=u.get("num_heads", 8),
+                                context_dim=u.get("context_dim", 768))
+    rt = SdeoRuntime(ucfg, vcfg, device=device)
+    model = ControlLDM(rt, cond_stage_model=cond_stage_model)
+    print(f"Loaded model config from [{config_path}]")
+    return model
