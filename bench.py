@@ -1,0 +1,194 @@
+"""bench.py -- headline benchmark of the MI355X-native canny2image hot path (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input = ONE IMAGE per GPU:
+hint block + cross-attention K/V precompute (once per image), 20 DDIM steps of ControlNet + ControlledUnet on the
+fused CFG pair (N=2) with the CFG/DDIM update, VAE decode and the uint8 post-process -- all on the GPU, inputs
+resident in HBM.  Images are sharded over ranks by image index (no data-path collective); the final latents are
+gathered once with RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     -- the dominant kernel (by device time) of one profiled image: algorithmic FLOPs of its launches /
+                  their summed HIP-event durations, against the dense fp16 MFMA peak (2.5 PFLOP/s).
+  cpu_baseline -- the oracle (oracle/sd_oracle.py = fp32 PyTorch restatement of the reference path, "port") timed
+                  on this host's cores on a bounded sample (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from stablediffusioneo_amd import spec as S                      # noqa: E402
+
+PEAK_TFLOPS_F16 = 2500.0            # dense fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic FLOPs (2*MAC over conv + GEMM + attention matmuls of the reference modules)
+FLOP_PER_STEP = {256: 0.486e12, 512: 2.173e12, 768: 5.843e12}
+FLOP_VAE = {256: 0.622e12, 512: 2.515e12, 768: 5.754e12}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4, help="timed images per GPU")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--ddim-steps", type=int, default=20)
+    ap.add_argument("--scale", type=float, default=9.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--config", default="sd15", choices=["sd15", "tiny"])
+    return ap.parse_args()
+
+
+def cpu_baseline(res, ddim_steps, scale):
+    """Oracle ("port" of the reference PyTorch path) on the host cores: ONE DDIM step = cond + uncond apply_model at
+    N=1 (the reference's two sequential passes, `cldm/ddim_hacked.py:190-191`), fp32, synthetic weights."""
+    from oracle import sd_oracle as O
+    from tests.common import make_inputs, randn
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    u = S.UNET_SD15
+    su = S.synth_state_dict(S.param_spec_unet(u), 0, S.NS_UNET)
+    sc = S.synth_state_dict(S.param_spec_controlnet(u), 0, S.NS_CONTROL)
+    up, cp, hc = S.unet_plan(u), S.unet_plan(u, False), S.hint_block_convs(u)
+    h = res // 8
+    x, ctx, hint = make_inputs(1, h, h)
+    ctx_u = randn((1, 77, 768), 2)
+    t = torch.tensor([951], dtype=torch.long)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        e_c = O.apply_model(su, sc, up, cp, hc, x, t, ctx, hint, [1.0] * 13)
+        e_u = O.apply_model(su, sc, up, cp, hc, x, t, ctx_u, hint, [1.0] * 13)
+        e = e_u + scale * (e_c - e_u)
+        O.ddim_step(x, e, 0.0047, 0.0058, 0.0, (1 - 0.0047) ** 0.5)
+        dt = time.perf_counter() - t0
+    return {"value": 1.0 / (ddim_steps * dt), "unit": "images/s", "cores": cores, "kind": "port",
+            "seconds_per_ddim_step": dt,
+            "sample": f"1 DDIM step (cond + uncond apply_model, N=1) of the fp32 oracle at {res}x{res}, "
+                      f"extrapolated x{ddim_steps}; VAE decode not included"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from stablediffusioneo_amd.cldm.cldm import ControlLDM
+    from stablediffusioneo_amd.cldm.ddim_hacked import DDIMSampler
+    from stablediffusioneo_amd.runtime import SdeoRuntime
+    from tests.common import X_T_SEED, make_hint, randn
+
+    ucfg, vcfg = (S.UNET_SD15, S.VAE_SD15) if a.config == "sd15" else (S.UNET_TINY, S.VAE_TINY)
+    rt = SdeoRuntime(ucfg, vcfg, device=dev)
+    rt.load_synthetic_device(0)
+    model = ControlLDM(rt)
+    sampler = DDIMSampler(model)
+    h = w = a.res // 8
+    hint = make_hint(1, a.res, a.res).to(dev)
+    ctx_c = randn((1, ucfg.context_len, ucfg.context_dim), 1).to(dev)
+    ctx_u = randn((1, ucfg.context_len, ucfg.context_dim), 2).to(dev)
+    cond = {"c_concat": [hint], "c_crossattn": [ctx_c]}
+    unc = {"c_concat": [hint], "c_crossattn": [ctx_u]}
+    loop_ev = []
+
+    def one_image(index, timed=True):
+        x_T = randn((1, 4, h, w), X_T_SEED + index).to(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        z, _ = sampler.sample(a.ddim_steps, 1, (4, h, w), cond, verbose=False, eta=0.0, unconditional_guidance_scale=a.scale,
+                              unconditional_conditioning=unc, x_T=x_T)
+        e1.record()
+        if timed:
+            loop_ev.append((e0, e1))
+        img = model.decode_first_stage_uint8(z)
+        return z, img
+
+    for i in range(a.warmup):
+        one_image(rank + i * world, timed=False)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    zs = []
+    for i in range(a.steps):
+        z, img = one_image(rank + i * world)      # image index -> rank: index % world == rank
+        zs.append(z)
+    zloc = torch.cat(zs).half()
+    if dist:
+        gathered = [torch.empty_like(zloc) for _ in range(world)]
+        dist.all_gather(gathered, zloc)             # the only collective: final latents, 32 KiB / image
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    loop_ms = sum(e0.elapsed_time(e1) for e0, e1 in loop_ev) / max(len(loop_ev), 1)
+    assert torch.isfinite(zloc.float()).all() and int(img.float().std() > 0), "degenerate output"
+
+    roof = None
+    if not a.no_roofline and rank == 0:
+        rt.profile_begin()
+        one_image(10_000, timed=False)
+        prof = rt.profile_end()
+        mm = [k for k in prof if k["flops"] > 0]
+        dom = max(mm, key=lambda k: k["total_ms"])
+        tot_ms = sum(k["total_ms"] for k in prof)
+        ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_TFLOPS_F16, 4), "traffic": None, "kernel": dom["kernel"],
+                "launches_per_image": dom["launches"], "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2),
+                "share_of_device_time": round(dom["total_ms"] / tot_ms, 3),
+                "by_kernel_ms_per_image": {k["kernel"]: round(k["total_ms"], 2) for k in
+                                           sorted(prof, key=lambda k: -k["total_ms"])}}
+
+    if rank == 0:
+        images = world * a.steps
+        per_image_s = elapsed / a.steps
+        flop_img = FLOP_PER_STEP.get(a.res, 0) * a.ddim_steps + FLOP_VAE.get(a.res, 0) if a.config == "sd15" else 0
+        out = {
+            "metric": "512x512 canny2image images/sec (20 DDIM steps); ms per UNet step reported alongside",
+            "value": round(images / elapsed, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(per_image_s * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "ms_per_unet_step": round(loop_ms / a.ddim_steps, 3),
+            "mfma_frac_whole_image": round(flop_img / per_image_s / 1e12 / PEAK_TFLOPS_F16, 4) if flop_img else None,
+            "config": {"workload": f"SD1.5 + ControlNet-canny {a.res}x{a.res}, batch=1 per GPU (CFG pair fused, N=2), "
+                                   f"{a.ddim_steps} DDIM steps + VAE decode, fp16 storage / fp32 accumulate (BASELINE configs[1])",
+                       "model_config": a.config, "images_per_gpu_per_step": 1, "ddim_steps": a.ddim_steps,
+                       "guidance_scale": a.scale, "parallelism": f"dp{world} (image index -> rank, RCCL all_gather of final latents)",
+                       "weights": "seeded synthetic (no checkpoint in the container)"},
+        }
+        if roof:
+            out["roofline"] = roof
+        if world == 1 and not a.no_cpu_baseline and a.config == "sd15":
+            out["cpu_baseline"] = cpu_baseline(a.res, a.ddim_steps, a.scale)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -117,7 +117,8 @@ int sdeo_destroy(sdeo_handle h);
 
 /* Weights: one call per checkpoint tensor, names exactly as in the reference state dict
  * ("model.diffusion_model.*", "control_model.*", "first_stage_model.*"; cldm/model.py:12-21).
- * host_data is a HOST pointer to fp32 data in PyTorch layout (OIHW conv, [out][in] linear).
+ * host_data points to fp32 data in PyTorch layout (OIHW conv, [out][in] linear); it may be a host OR a device
+ * pointer (copied with hipMemcpyDefault).
  * Unknown names return 0 and are ignored when `strict` is 0.  After the last tensor call
  * sdeo_finalize_weights (fails listing what is missing). */
 int sdeo_load_weight(sdeo_handle h, const char* name, const float* host_data, const int64_t* dims, int ndim, int strict);
@@ -164,6 +165,13 @@ int sdeo_vae_decode(sdeo_handle h, const float* z, int n, float* images, uint8_t
 
 /* bytes of device memory the handle owns (weights + arena) */
 size_t sdeo_device_bytes(sdeo_handle h);
+
+/* Per-kernel timing for bench.py's roofline: between begin and end every launch of the net-level calls is
+ * bracketed by HIP events on the stream it runs on; end synchronises the device and returns a JSON array
+ * [{"kernel", "launches", "total_ms", "flops", "bytes"}] (algorithmic flops / bytes summed over the launches).
+ * Do not time whole steps while profiling is on (the events serialise nothing but add host overhead). */
+int sdeo_profile_begin(sdeo_handle h);
+const char* sdeo_profile_end(sdeo_handle h);
 
 #ifdef __cplusplus
 }

@@ -335,6 +335,13 @@ size_t conv_gemm_workspace_bytes(const ConvGemm& p) {
   return pl.splitk > 1 ? (size_t)pl.splitk * p.M * p.N * sizeof(float) : 0;
 }
 
+const char* conv_gemm_kernel_name(const ConvGemm& p) {
+  static const char* names[] = {"conv_gemm_kernel<128,128,64,false>", "conv_gemm_kernel<128,64,64,false>",
+                                "conv_gemm_kernel<64,64,64,false>", "conv_gemm_kernel<128,64,32,true>",
+                                "conv_gemm_kernel<64,64,32,true>"};
+  return names[make_plan(p).tile];
+}
+
 template <int BM, int BN, int BK, bool G>
 static int launch(const KP& kp, int tiles, hipStream_t stream) {
   constexpr int smem = 2 * (BM + BN) * BK * 2;

@@ -35,6 +35,8 @@ struct ConvGemm {
 };
 int conv_gemm(const ConvGemm& p, hipStream_t stream);
 size_t conv_gemm_workspace_bytes(const ConvGemm& p);
+// name of the kernel instantiation the launcher will pick (for profiles; matches the rocprof kernel name's template args)
+const char* conv_gemm_kernel_name(const ConvGemm& p);
 
 // ------------------------------------------------------------------------------------------
 // GroupNorm (NHWC fp16, fp32 statistics, eps honoured) + optional SiLU; two launches:

@@ -182,8 +182,17 @@ struct T {           // fp16 activation view: rows x c, row stride ld; (n,h,w) w
   int rows() const { return n * h * w; }
 };
 
-typedef std::function<int(hipStream_t)> Op;
+struct Op {          // one launch of a program + what it is for the profiler
+  std::function<int(hipStream_t)> fn;
+  const char* key = "other";
+  double flops = 0, bytes = 0;
+  template <class F>
+  Op(F f) : fn(std::move(f)) {}
+  int operator()(hipStream_t s) const { return fn(s); }
+};
 typedef std::vector<Op> Program;
+
+struct ProfRec { const char* key; double flops, bytes; hipEvent_t a, b; };
 
 }  // namespace
 
@@ -227,6 +236,10 @@ struct sdeo_handle_s {
   Program p_hint, p_ctx_cn, p_ctx_unet, p_cn, p_cn_export, p_ctrl_import, p_unet_ctrl, p_unet_noctrl, p_vae;
   std::vector<size_t> ctrl_elems;
   size_t device_bytes = 0;
+  // profiling (sdeo_profile_*): HIP events around every launch of the next programs
+  bool profiling = false;
+  std::vector<ProfRec> prof;
+  std::string prof_report;
 };
 
 namespace {
@@ -434,7 +447,10 @@ struct Builder {
     if (t.off != (size_t)-1) arena->release(t.off);
     t.off = (size_t)-1;
   }
-  void push(Op op) { if (!dry) prog->push_back(std::move(op)); }
+  void push(Op op, const char* key = "elementwise", double flops = 0, double bytes = 0) {
+    op.key = key; op.flops = flops; op.bytes = bytes;
+    if (!dry) prog->push_back(std::move(op));
+  }
 
   const WEntry* W(const std::string& name) {
     auto it = e->windex.find(name);
@@ -455,7 +471,8 @@ struct Builder {
       p.workspace_bytes = eng->splitk_ws_bytes;
       if (scale_host) p.scale = *scale_host;
       return conv_gemm(p, s);
-    });
+    }, conv_gemm_kernel_name(p), 2.0 * p.M * p.N * p.K,
+       2.0 * ((double)p.M * p.Cin * (p.R * p.S > 1 ? 1 : 1) + (double)p.N * p.K + (double)p.M * p.N));
   }
 
   // conv on an image view; weights by name (".weight"/".bias" appended)
@@ -516,7 +533,8 @@ struct Builder {
     max_gn = std::max(max_gn, (size_t)B * gn_chunks(HW) * 32 * 2 * sizeof(float));
     Engine* eng = e;
     const f16* xp = x.p; f16* yp = y.p; const int ldx = x.ld, ldy = y.ld;
-    push([=](hipStream_t s) { return groupnorm_nhwc(yp, ldy, xp, ldx, g, b, B, HW, C, 32, eps, silu_, eng->gn_ws, s); });
+    push([=](hipStream_t s) { return groupnorm_nhwc(yp, ldy, xp, ldx, g, b, B, HW, C, 32, eps, silu_, eng->gn_ws, s); }, "groupnorm", 0,
+         3.0 * 2.0 * B * HW * C);
     if (out) y.off = (size_t)-1;
     return y;
   }
@@ -526,14 +544,15 @@ struct Builder {
     const float* g = vptr(name + ".weight");
     const float* b = vptr(name + ".bias");
     const f16* xp = x.p; f16* yp = y.p; const int ldx = x.ld, ldy = y.ld, rows = x.rows(), C = x.c;
-    push([=](hipStream_t s) { return layernorm(yp, ldy, xp, ldx, g, b, rows, C, 1e-5f, s); });
+    push([=](hipStream_t s) { return layernorm(yp, ldy, xp, ldx, g, b, rows, C, 1e-5f, s); }, "layernorm", 0, 4.0 * rows * C);
     return y;
   }
 
   void attn(const T& o, const f16* q, int ldq, const f16* k, int ldk, const f16* vt, int ldvt, int B, int H, int Tq, int Tk, int TkS, int TkSv, int d) {
     f16* op = o.p; const int ldo = o.ld;
     const float scale = 1.0f / sqrtf((float)d);
-    push([=](hipStream_t s) { return attention(op, ldo, q, ldq, k, ldk, vt, ldvt, B, H, Tq, Tk, TkS, TkSv, d, scale, s); });
+    push([=](hipStream_t s) { return attention(op, ldo, q, ldq, k, ldk, vt, ldvt, B, H, Tq, Tk, TkS, TkSv, d, scale, s); }, "attention",
+         4.0 * B * H * (double)Tq * Tk * d, 2.0 * B * H * d * (2.0 * Tq + 2.0 * Tk));
   }
 };
 
@@ -674,9 +693,21 @@ struct Built {
   T hint_feat;
 };
 
-static int run(const Program& p, hipStream_t s) {
+static int run(Engine* e, const Program& p, hipStream_t s) {
+  if (!e->profiling) {
+    for (auto& op : p) {
+      if (int rc = op(s)) return rc;
+    }
+    return 0;
+  }
   for (auto& op : p) {
+    ProfRec r{op.key, op.flops, op.bytes, nullptr, nullptr};
+    SDEO_HIP(hipEventCreate(&r.a));
+    SDEO_HIP(hipEventCreate(&r.b));
+    SDEO_HIP(hipEventRecord(r.a, s));
     if (int rc = op(s)) return rc;
+    SDEO_HIP(hipEventRecord(r.b, s));
+    e->prof.push_back(r);
   }
   return 0;
 }
@@ -1085,7 +1116,7 @@ int sdeo_load_weight(sdeo_handle h, const char* name, const float* host_data, co
   if (h->stage == nullptr) {
     SDEO_HIP(hipMalloc((void**)&h->stage, h->stage_bytes));
   }
-  SDEO_HIP(hipMemcpy(h->stage, host_data, n * sizeof(float), hipMemcpyHostToDevice));
+  SDEO_HIP(hipMemcpy(h->stage, host_data, n * sizeof(float), hipMemcpyDefault));
   void* dst = h->wslab + w.off;
   int rc = 0;
   switch (w.kind) {
@@ -1183,12 +1214,12 @@ static int stage_inputs(sdeo_handle h, const float* x, const float* hint, const 
   if (t) if (int rc = copy_in(h->in_t, t, (size_t)h->N * 8, s)) return rc;
   if (hint && hint_is_new) {
     if (int rc = copy_in(h->in_hint, hint, (size_t)h->N * c.hint_channels * px * 64 * 4, s)) return rc;
-    if (int rc = run(h->p_hint, s)) return rc;
+    if (int rc = run(h, h->p_hint, s)) return rc;
   }
   if (ctx) {
     if (int rc = copy_in(h->in_ctx, ctx, (size_t)h->N * c.context_len * c.context_dim * 4, s)) return rc;
-    if (ctx_for_net & 1) if (int rc = run(h->p_ctx_unet, s)) return rc;
-    if (ctx_for_net & 2) if (int rc = run(h->p_ctx_cn, s)) return rc;
+    if (ctx_for_net & 1) if (int rc = run(h, h->p_ctx_unet, s)) return rc;
+    if (ctx_for_net & 2) if (int rc = run(h, h->p_ctx_cn, s)) return rc;
   }
   return 0;
 }
@@ -1207,8 +1238,8 @@ int sdeo_controlnet_forward(sdeo_handle h, const float* x_noisy, const float* hi
   SDEO_CHECK(!hint_new || hint, "sdeo_controlnet_forward: hint required");
   SDEO_CHECK(!ctx_new || context, "sdeo_controlnet_forward: context required");
   if (int rc = stage_inputs(h, x_noisy, hint, timesteps, ctx_new ? context : nullptr, hint_new, 2, s)) return rc;
-  if (int rc = run(h->p_cn, s)) return rc;
-  if (int rc = run(h->p_cn_export, s)) return rc;
+  if (int rc = run(h, h->p_cn, s)) return rc;
+  if (int rc = run(h, h->p_cn_export, s)) return rc;
   for (size_t i = 0; i < h->ctrl_elems.size(); ++i)
     if (controls[i]) if (int rc = copy_in(controls[i], h->out_ctrl[i], h->ctrl_elems[i] * 4, s)) return rc;
   return 0;
@@ -1230,10 +1261,10 @@ int sdeo_unet_forward(sdeo_handle h, const float* x_noisy, const int64_t* timest
       SDEO_CHECK(controls[i], "sdeo_unet_forward: control %zu is null", i);
       if (int rc = copy_in(h->in_ctrl[i], controls[i], h->ctrl_elems[i] * 4, s)) return rc;
     }
-    if (int rc = run(h->p_ctrl_import, s)) return rc;
-    if (int rc = run(h->p_unet_ctrl, s)) return rc;
+    if (int rc = run(h, h->p_ctrl_import, s)) return rc;
+    if (int rc = run(h, h->p_unet_ctrl, s)) return rc;
   } else {
-    if (int rc = run(h->p_unet_noctrl, s)) return rc;
+    if (int rc = run(h, h->p_unet_noctrl, s)) return rc;
   }
   return copy_in(eps, h->out_eps, (size_t)h->N * h->cfg.out_channels * h->lh * h->lw * 4, s);
 }
@@ -1252,10 +1283,10 @@ int sdeo_apply_model(sdeo_handle h, const float* x_noisy, const float* hint, con
   h->only_mid = only_mid_control;
   for (int i = 0; i < 13; ++i) h->scales[i] = host_control_scales ? host_control_scales[i] : 1.0f;
   if (no_control) {
-    if (int rc = run(h->p_unet_noctrl, s)) return rc;
+    if (int rc = run(h, h->p_unet_noctrl, s)) return rc;
   } else {
-    if (int rc = run(h->p_cn, s)) return rc;
-    if (int rc = run(h->p_unet_ctrl, s)) return rc;
+    if (int rc = run(h, h->p_cn, s)) return rc;
+    if (int rc = run(h, h->p_unet_ctrl, s)) return rc;
   }
   return copy_in(eps, h->out_eps, (size_t)h->N * h->cfg.out_channels * h->lh * h->lw * 4, s);
 }
@@ -1268,7 +1299,7 @@ int sdeo_vae_decode(sdeo_handle h, const float* z, int n, float* images, uint8_t
   const size_t px = (size_t)h->lh * h->lw;
   for (int i = 0; i < n; ++i) {
     if (int rc = copy_in(h->vae_in, z + (size_t)i * c.vae_z_channels * px, (size_t)c.vae_z_channels * px * 4, s)) return rc;
-    if (int rc = run(h->p_vae, s)) return rc;
+    if (int rc = run(h, h->p_vae, s)) return rc;
     if (images)
       if (int rc = copy_in(images + (size_t)i * c.vae_out_ch * px * 64, h->vae_out, (size_t)c.vae_out_ch * px * 64 * 4, s)) return rc;
     if (images_u8)
@@ -1278,5 +1309,42 @@ int sdeo_vae_decode(sdeo_handle h, const float* z, int n, float* images, uint8_t
 }
 
 size_t sdeo_device_bytes(sdeo_handle h) { return h ? h->device_bytes : 0; }
+
+int sdeo_profile_begin(sdeo_handle h) {
+  SDEO_CHECK(h, "sdeo_profile_begin: null handle");
+  for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  h->prof.clear();
+  h->profiling = true;
+  return 0;
+}
+
+const char* sdeo_profile_end(sdeo_handle h) {
+  if (!h) return "";
+  h->profiling = false;
+  (void)hipDeviceSynchronize();
+  struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0; };
+  std::vector<std::pair<std::string, Agg>> aggs;
+  for (auto& r : h->prof) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+    size_t i = 0;
+    for (; i < aggs.size(); ++i) if (aggs[i].first == r.key) break;
+    if (i == aggs.size()) aggs.push_back({r.key, Agg()});
+    aggs[i].second.n += 1; aggs[i].second.ms += ms; aggs[i].second.flops += r.flops; aggs[i].second.bytes += r.bytes;
+  }
+  h->prof.clear();
+  std::string out = "[";
+  char buf[512];
+  for (size_t i = 0; i < aggs.size(); ++i) {
+    snprintf(buf, sizeof(buf), "%s{\"kernel\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+             i ? ", " : "", aggs[i].first.c_str(), aggs[i].second.n, aggs[i].second.ms, aggs[i].second.flops, aggs[i].second.bytes);
+    out += buf;
+  }
+  out += "]";
+  h->prof_report = out;
+  return h->prof_report.c_str();
+}
 
 }  // extern "C"

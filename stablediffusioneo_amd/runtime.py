@@ -86,6 +86,38 @@ class SdeoRuntime:
             self.load_tensor(name, S.synth_tensor(name, shape, seed))
         check(self.lib.sdeo_finalize_weights(self.handle), "finalize_weights")
 
+    def load_synthetic_device(self, seed: int = 0):
+        """Synthetic weights drawn on the GPU (device generator) -- fast path for bench.py; NOT reproducible on the
+        CPU, so parity tests use load_synthetic instead.  Same distributions as spec.synth_tensor."""
+        g = torch.Generator(device=self.device)
+        g.manual_seed(seed)
+        for name, shape in self.expected_weights().items():
+            leaf = name.rsplit(".", 1)[-1]
+            if len(shape) == 1:
+                is_norm = any(t in name for t in (".norm", "in_layers.0", "out_layers.0", "out.0", "norm_out"))
+                t = torch.randn(shape, generator=g, device=self.device)
+                t = 1.0 + 0.1 * t if (leaf == "weight" and is_norm) else 0.02 * t
+            else:
+                fan_in = 1
+                for d in shape[1:]:
+                    fan_in *= d
+                t = torch.randn(shape, generator=g, device=self.device) * (1.0 / fan_in) ** 0.5
+            t = t.contiguous()
+            dims = (C.c_int64 * len(shape))(*shape)
+            check(self.lib.sdeo_load_weight(self.handle, name.encode(), C.c_void_p(t.data_ptr()), dims, C.c_int(len(shape)),
+                                            C.c_int(1)), f"load_weight({name})")
+        check(self.lib.sdeo_finalize_weights(self.handle), "finalize_weights")
+
+    # ---------------------------------------------------------------- profiling
+    def profile_begin(self):
+        check(self.lib.sdeo_profile_begin(self.handle), "profile_begin")
+
+    def profile_end(self):
+        import json
+        self.lib.sdeo_profile_end.restype = C.c_char_p
+        self.lib.sdeo_profile_end.argtypes = [C.c_void_p]
+        return json.loads(self.lib.sdeo_profile_end(self.handle).decode())
+
     # ---------------------------------------------------------------- shapes
     def configure(self, n: int, h: int, w: int):
         if (n, h, w) != (self.n, self.h, self.w):
