@@ -135,8 +135,9 @@ def main():
         zs.append(z)
     zloc = torch.cat(zs).half()
     if dist:
-        gathered = [torch.empty_like(zloc) for _ in range(world)]
-        dist.all_gather(gathered, zloc)             # the only collective: final latents, 32 KiB / image
+        from stablediffusioneo_amd.sharding import gather_latents
+        zall = gather_latents(zloc, world * a.steps)   # the only collective: final latents, 32 KiB / image
+        assert zall.shape[0] == world * a.steps
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

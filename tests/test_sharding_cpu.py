@@ -1,0 +1,69 @@
+"""The N>1 path on CPU: world_size-2 gloo processes shard images by index and all-gather the final latents."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from stablediffusioneo_amd.sharding import gather_latents, shard_indices
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def fake_latent(i):
+    g = torch.Generator().manual_seed(2946901 + i)
+    return torch.randn((4, 8, 8), generator=g)
+
+
+def _worker(rank, world, port, total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        idx = shard_indices(total, rank, world)
+        local = torch.stack([fake_latent(i) for i in idx]) if idx else torch.empty((0, 4, 8, 8))
+        full = gather_latents(local, total)
+        ref = torch.stack([fake_latent(i) for i in range(total)])
+        q.put((rank, bool(torch.equal(full, ref)), idx))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [8, 5, 2])
+def test_gloo_world2_image_sharding(total):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    seen = sorted(i for _, _, idx in res for i in idx)
+    assert seen == list(range(total))          # every image exactly once, no overlap
+
+
+def test_shard_indices_properties():
+    for world in (1, 2, 4, 8):
+        for total in (0, 1, 7, 8, 16):
+            allidx = [i for r in range(world) for i in shard_indices(total, r, world)]
+            assert sorted(allidx) == list(range(total))
+    with pytest.raises(ValueError):
+        shard_indices(4, 2, 2)
+
+
+def test_single_process_passthrough():
+    z = torch.randn(3, 4, 8, 8)
+    assert gather_latents(z, 3) is z
