@@ -13,9 +13,17 @@
 //  * weights are the MFMA "A" operand (rows = output channel), activations the "B" operand (cols =
 //    output pixel): each lane then ends up with 4 consecutive output channels of one pixel, i.e. an
 //    8-byte NHWC store, and bias / time-embedding / residual / SiLU / scale are applied in registers.
-//  * register-staged double buffering (global -> VGPR early, VGPR -> LDS after the MFMA phase), LDS
-//    tiles XOR-swizzled so the ds_read_b128 fragment reads are bank-conflict free.
-//  * split-K over blockIdx.z for the weight-bandwidth-bound deep levels (M = 128..512, K up to 23k).
+//  * main kernel (`conv_gemm_dma_kernel`): global_load_lds (LDS-DMA, 16 B per lane) into a ring of LDS
+//    stages, counted s_waitcnt vmcnt(N) + raw s_barrier so 1-3 K-steps of loads stay in flight across
+//    the barrier; padding rows read a zero page so every lane issues the same number of DMAs; the XOR
+//    swizzle that makes the ds_read_b128 fragment reads bank-conflict free is applied to the per-lane
+//    SOURCE address (the DMA destination is lane-linear) and to the fragment reads.
+//  * fallback kernel (`conv_gemm_kernel`): register-staged double buffering, used when Cin is not a
+//    multiple of 64 (first convs, hint block, reduced test configs).
+//  * split-K over blockIdx.z for the weight-bandwidth-bound deep levels (M = 128..512, K up to 23k) and to
+//    fill 256 CUs when M x N is small.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace sdeo {
@@ -36,8 +44,11 @@ struct KP {
   int act, bias_per_row;
   float scale;
   int nk, nk_per_split, splitk;
-  int tiles_m;
+  int tiles_m, tiles_n;
 };
+
+// 256 bytes of zeros: DMA source for padded / out-of-range rows
+__device__ __attribute__((aligned(256))) const unsigned int g_zero_page[64] = {0};
 
 template <int BK>
 __device__ __forceinline__ int swz_chunk(int row, int chunk) {
@@ -46,6 +57,186 @@ __device__ __forceinline__ int swz_chunk(int row, int chunk) {
   return chunk ^ (((row >> 3) & 1) * 3);
 }
 
+// ---- epilogue shared by both kernels: lane holds n = nb + fq*4 + {0..3} (4 consecutive channels) of pixel m
+template <int NI, int MI, int TM, int TN>
+__device__ __forceinline__ void epilogue(const KP& p, f32x4 (&acc)[NI][MI], int m0, int n0, int wm, int wn, int frow, int fq, int z) {
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    const int m = m0 + wm * TM + j * 16 + frow;
+    if (m >= p.M) continue;
+    const int b = p.bias2 ? m / p.HoWo : 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int n = n0 + wn * TN + i * 16 + fq * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      if (p.splitk > 1) {
+        *reinterpret_cast<f32x4*>(p.ws + ((size_t)z * p.M + m) * p.N + n) = v;
+        continue;
+      }
+      if (p.bias) {
+        if (p.bias_per_row) v += p.bias[m];
+        else v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      }
+      if (p.bias2) v += *reinterpret_cast<const f32x4*>(p.bias2 + (size_t)b * p.ld_bias2 + n);
+      if (p.act == 1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
+      }
+      v *= p.scale;
+      if (p.res) {
+        const f16x4 r = *reinterpret_cast<const f16x4*>(p.res + (size_t)m * p.ldres + n);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] += (float)r[t];
+      }
+      if (p.y32) {
+        *reinterpret_cast<f32x4*>(p.y32 + (size_t)m * p.ldy + n) = v;
+      } else {
+        f16x4 o;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = (f16)v[t];
+        *reinterpret_cast<f16x4*>(p.y + (size_t)m * p.ldy + n) = o;
+      }
+    }
+  }
+}
+
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (observed, speed only), so give each
+// XCD a contiguous run of tiles (bijective for any tile count): neighbouring tiles share a weight panel in L2.
+__device__ __forceinline__ int xcd_remap(int wg, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// main kernel: LDS-DMA ring, Cin % 64 == 0
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int STAGES>
+__global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KP p) {
+  constexpr int BK = 64, CPR = 8, RPP = 32;
+  constexpr int XP = BM / RPP, WP = BN / RPP, L = XP + WP;     // DMA instructions per thread per stage
+  constexpr int TM = BM / 2, TN = BN / 2, MI = TM / 16, NI = TN / 16;
+  constexpr int XBYTES = BM * BK * 2, WBYTES = BN * BK * 2, STAGE = XBYTES + WBYTES;
+  constexpr int PF = STAGES - 1;                                // K-steps of loads issued ahead of the compute
+  static_assert(PF >= 1 && PF <= 3, "ring depth");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.z;
+  const int kbeg = z * p.nk_per_split;
+  const int kend = min(p.nk, kbeg + p.nk_per_split);
+  const int nk = kend - kbeg;
+
+  const int chunk = tid & 7, lrow = tid >> 3;
+  const int cl = chunk ^ ((lrow >> 1) & 7);        // logical k-chunk this lane fetches into its (linear) LDS slot
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  int pixbase[XP], hb[XP], wb[XP];
+  bool mvalid[XP];
+  const int Hv = p.ups ? 2 * p.Hi : p.Hi, Wv = p.ups ? 2 * p.Wi : p.Wi;
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int m = m0 + lrow + i * RPP;
+    mvalid[i] = m < p.M;
+    const int mm = mvalid[i] ? m : 0;
+    const int b = mm / p.HoWo;
+    const int rem = mm - b * p.HoWo;
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+    pixbase[i] = b * p.Hi * p.Wi;
+    hb[i] = ho * p.stride - p.pad;
+    wb[i] = wo * p.stride - p.pad;
+  }
+  const f16* wrow[WP];
+#pragma unroll
+  for (int i = 0; i < WP; ++i) {
+    const int n = n0 + lrow + i * RPP;
+    wrow[i] = n < p.N ? p.w + (size_t)n * p.ldw + cl * 8 : nullptr;
+  }
+  const int tapsteps = p.Cin >> 6;
+
+  // issue the DMAs of K-step kt into ring slot `slot` (every lane issues exactly L of them)
+  auto issue = [&](int kt, int slot) {
+    const int tap = kt / tapsteps;
+    const int c0 = ((kt - tap * tapsteps) << 6) + cl * 8;
+    const int r = tap / p.S, s = tap - r * p.S;
+    char* xs = smem + slot * STAGE + wave * 1024;
+    char* wsm = xs + XBYTES;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      int hi = hb[i] + r, wi = wb[i] + s;
+      const bool ok = mvalid[i] && hi >= 0 && hi < Hv && wi >= 0 && wi < Wv;
+      if (p.ups) { hi >>= 1; wi >>= 1; }
+      const char* src = ok ? reinterpret_cast<const char*>(p.x + (size_t)(pixbase[i] + hi * p.Wi + wi) * p.ldx + c0) : zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(xs + i * 4096), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+      const char* src = wrow[i] ? reinterpret_cast<const char*>(wrow[i] + (size_t)kt * BK) : zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(wsm + i * 4096), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fq = lane >> 4;
+
+  if (nk > 0) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+      if (s < nk) issue(kbeg + s, s);
+    for (int it = 0; it < nk; ++it) {
+      // retire the DMAs of K-step `it`: all but the (newer) steps still allowed in flight
+      const int ahead = min(PF - 1, nk - 1 - it);
+      if (ahead >= 2) wait_vmcnt<2 * L>();
+      else if (ahead == 1) wait_vmcnt<L>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();      // step `it` visible to every wave; everyone is done reading slot (it-1)%STAGES
+      if (it + PF < nk) issue(kbeg + it + PF, (it + PF) % STAGES);
+      const char* xs = smem + (it % STAGES) * STAGE;
+      const char* wsm = xs + XBYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        f16x8 wf[NI], xf[MI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int row = wn * TN + i * 16 + frow;
+          wf[i] = *reinterpret_cast<const f16x8*>(wsm + row * 128 + swz_chunk<64>(row, kk * 4 + fq) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+          const int row = wm * TM + j * 16 + frow;
+          xf[j] = *reinterpret_cast<const f16x8*>(xs + row * 128 + swz_chunk<64>(row, kk * 4 + fq) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < MI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  epilogue<NI, MI, TM, TN>(p, acc, m0, n0, wm, wn, frow, fq, z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fallback kernel: register-staged double buffer (any Cin % 8 == 0)
+// ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int BK, bool GENERIC>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const KP p) {
   constexpr int CPR = BK / 8;         // 16-byte chunks per tile row
@@ -74,7 +265,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KP p) {
   const int chunk = tid % CPR;
   const int lrow = tid / CPR;
 
-  // ---- per-thread gather state for the activation rows this thread stages
   int pixbase[XP], hb[XP], wb[XP];
   bool mvalid[XP];
   const int Hv = p.ups ? 2 * p.Hi : p.Hi, Wv = p.ups ? 2 * p.Wi : p.Wi;
@@ -195,50 +385,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KP p) {
       __syncthreads();
     }
   }
-
-  // ---- epilogue: lane holds n = nb + fq*4 + {0..3} (4 consecutive output channels) of pixel m
-#pragma unroll
-  for (int j = 0; j < MI; ++j) {
-    const int m = m0 + wm * TM + j * 16 + frow;
-    if (m >= p.M) continue;
-    const int b = p.bias2 ? m / p.HoWo : 0;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int n = n0 + wn * TN + i * 16 + fq * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[i][j];
-      if (p.splitk > 1) {
-        *reinterpret_cast<f32x4*>(p.ws + ((size_t)z * p.M + m) * p.N + n) = v;
-        continue;
-      }
-      if (p.bias) {
-        if (p.bias_per_row) {
-          v += p.bias[m];
-        } else {
-          v += *reinterpret_cast<const f32x4*>(p.bias + n);
-        }
-      }
-      if (p.bias2) v += *reinterpret_cast<const f32x4*>(p.bias2 + (size_t)b * p.ld_bias2 + n);
-      if (p.act == 1) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
-      }
-      v *= p.scale;
-      if (p.res) {
-        const f16x4 r = *reinterpret_cast<const f16x4*>(p.res + (size_t)m * p.ldres + n);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] += (float)r[t];
-      }
-      if (p.y32) {
-        *reinterpret_cast<f32x4*>(p.y32 + (size_t)m * p.ldy + n) = v;
-      } else {
-        f16x4 o;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) o[t] = (f16)v[t];
-        *reinterpret_cast<f16x4*>(p.y + (size_t)m * p.ldy + n) = o;
-      }
-    }
-  }
+  epilogue<NI, MI, TM, TN>(p, acc, m0, n0, wm, wn, frow, fq, z);
 }
 
 // split-K: sum the fp32 partial slabs and apply the epilogue. One thread per 4 output channels.
@@ -278,13 +425,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KP p) {
 // ------------------------------------------------------------------------------------------------
 // host side: tile / split-K selection and launch
 // ------------------------------------------------------------------------------------------------
-struct TileCfg { int bm, bn, bk; bool generic; float weight; };
+enum TileKind { TK_DMA, TK_GENERIC };
+struct TileCfg { int bm, bn, bk, stages; TileKind kind; float weight; int wg_per_cu; const char* name; };
 static const TileCfg kTiles[] = {
-    {128, 128, 64, false, 1.00f},
-    {128, 64, 64, false, 0.90f},
-    {64, 64, 64, false, 0.72f},
-    {128, 64, 32, true, 0.90f},
-    {64, 64, 32, true, 0.72f},
+    {128, 128, 64, 3, TK_DMA, 1.00f, 1, "conv_gemm_dma_kernel<128,128,3>"},
+    {128, 64, 64, 3, TK_DMA, 0.85f, 2, "conv_gemm_dma_kernel<128,64,3>"},
+    {64, 64, 64, 4, TK_DMA, 0.65f, 2, "conv_gemm_dma_kernel<64,64,4>"},
+    {128, 64, 32, 2, TK_GENERIC, 0.85f, 3, "conv_gemm_kernel<128,64,32,true>"},
+    {64, 64, 32, 2, TK_GENERIC, 0.65f, 4, "conv_gemm_kernel<64,64,32,true>"},
 };
 static const int kNumTiles = 5;
 static const int kNumCU = 256;
@@ -293,41 +441,50 @@ struct Plan { int tile; int splitk; int nk; int tiles_m, tiles_n; };
 
 static bool is_fast(const ConvGemm& p) { return p.Cin % 64 == 0; }
 
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 static Plan make_plan(const ConvGemm& p) {
-  Plan pl{};
+  Plan best{};
   const bool fast = is_fast(p);
-  float best = -1.f;
+  const int force_tile = p.force_tile >= 0 ? p.force_tile : env_int("SDEO_FORCE_TILE", -1);
+  const int force_sk = p.force_splitk > 0 ? p.force_splitk : env_int("SDEO_FORCE_SPLITK", 0);
+  float best_t = 1e30f;
   for (int t = 0; t < kNumTiles; ++t) {
     const TileCfg& c = kTiles[t];
-    if (c.generic == fast) continue;
-    if (p.force_tile >= 0 && p.force_tile != t) continue;
+    if ((c.kind == TK_DMA) != fast) continue;
+    if (force_tile >= 0 && force_tile != t && (kTiles[force_tile].kind == TK_DMA) == fast) continue;
     const int tmn = cdiv(p.M, c.bm), tnn = cdiv(p.N, c.bn);
-    const float eff = ((float)p.M * p.N) / ((float)tmn * c.bm * tnn * c.bn);
-    const float tiles = (float)tmn * tnn;
-    // fraction of the chip busy (up to 2 resident blocks per CU), discounted by tile efficiency
-    float fill = tiles / (2.0f * kNumCU);
-    if (fill > 1.f) fill = 1.f;
-    const float score = eff * c.weight * (0.25f + 0.75f * fill);
-    if (score > best) { best = score; pl.tile = t; pl.tiles_m = tmn; pl.tiles_n = tnn; }
+    const int tiles = tmn * tnn;
+    const int nk = cdiv(p.K, c.bk);
+    const int slots = kNumCU * c.wg_per_cu;
+    // candidate split-K factors: 1 and whatever fills the chip once
+    int cands[3] = {1, 0, 0};
+    int ncand = 1;
+    if (tiles < slots && nk >= 8) {
+      int sk = slots / tiles;
+      if (sk > nk / 4) sk = nk / 4;
+      if (sk > 16) sk = 16;
+      if (sk >= 2) cands[ncand++] = sk;
+      if (sk >= 4) cands[ncand++] = sk / 2;
+    }
+    if (force_sk > 0) { cands[0] = force_sk > nk ? nk : force_sk; ncand = 1; }
+    for (int ci = 0; ci < ncand; ++ci) {
+      int sk = cands[ci];
+      const int per = cdiv(nk, sk);
+      sk = cdiv(nk, per);
+      // crude time model (arbitrary units): waves of workgroups x K-steps per workgroup x cost per step,
+      // plus fixed prologue/epilogue and the split-K slab traffic
+      const float rounds = (float)cdiv(tiles * sk, slots);
+      const float step_cost = (float)(c.bm * c.bn) / (128.f * 128.f) / c.weight;
+      float tcost = rounds * (per * step_cost + 3.0f);
+      if (sk > 1) tcost += 2.0f + (float)sk * p.M * p.N * 8.0f / 4.0e6f;   // write + read of fp32 partials
+      if (tcost < best_t) { best_t = tcost; best = Plan{t, sk, nk, tmn, tnn}; }
+    }
   }
-  const TileCfg& c = kTiles[pl.tile];
-  pl.nk = cdiv(p.K, c.bk);
-  int sk = 1;
-  const int tiles = pl.tiles_m * pl.tiles_n;
-  if (p.force_splitk > 0) {
-    sk = p.force_splitk;
-  } else if (tiles < kNumCU && pl.nk >= 16) {
-    sk = cdiv(kNumCU + kNumCU / 2, tiles);
-    if (sk > pl.nk / 8) sk = pl.nk / 8;
-    if (sk > 16) sk = 16;
-    if (sk < 1) sk = 1;
-  }
-  if (sk > pl.nk) sk = pl.nk;
-  // drop empty splits
-  const int per = cdiv(pl.nk, sk);
-  sk = cdiv(pl.nk, per);
-  pl.splitk = sk;
-  return pl;
+  return best;
 }
 
 size_t conv_gemm_workspace_bytes(const ConvGemm& p) {
@@ -335,24 +492,16 @@ size_t conv_gemm_workspace_bytes(const ConvGemm& p) {
   return pl.splitk > 1 ? (size_t)pl.splitk * p.M * p.N * sizeof(float) : 0;
 }
 
-const char* conv_gemm_kernel_name(const ConvGemm& p) {
-  static const char* names[] = {"conv_gemm_kernel<128,128,64,false>", "conv_gemm_kernel<128,64,64,false>",
-                                "conv_gemm_kernel<64,64,64,false>", "conv_gemm_kernel<128,64,32,true>",
-                                "conv_gemm_kernel<64,64,32,true>"};
-  return names[make_plan(p).tile];
-}
+const char* conv_gemm_kernel_name(const ConvGemm& p) { return kTiles[make_plan(p).tile].name; }
 
-template <int BM, int BN, int BK, bool G>
-static int launch(const KP& kp, int tiles, hipStream_t stream) {
-  constexpr int smem = 2 * (BM + BN) * BK * 2;
-  static bool attr_done = false;
-  if (!attr_done) {
-    SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, BK, G>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_done = true;
+template <typename K>
+static int launch_k(K kernel, int smem, bool* attr_done, const KP& kp, int tiles, hipStream_t stream) {
+  if (!*attr_done) {
+    SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    *attr_done = true;
   }
   dim3 grid(tiles, 1, kp.splitk);
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, G>), grid, dim3(256), smem, stream, kp);
+  hipLaunchKernelGGL(kernel, grid, dim3(256), smem, stream, kp);
   SDEO_HIP(hipGetLastError());
   return 0;
 }
@@ -368,6 +517,8 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
   SDEO_CHECK(p.M == p.B * p.Ho * p.Wo, "conv_gemm: M=%d != B*Ho*Wo=%d", p.M, p.B * p.Ho * p.Wo);
   SDEO_CHECK(p.ldy % 4 == 0 && p.ldy >= p.N, "conv_gemm: ldy=%d", p.ldy);
   SDEO_CHECK(!p.res || p.ldres % 4 == 0, "conv_gemm: ldres=%d", p.ldres);
+  SDEO_CHECK((reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.w) & 15) == 0,
+             "conv_gemm: operands must be 16-byte aligned");
   {
     const int Hv = p.ups ? 2 * p.Hi : p.Hi, Wv = p.ups ? 2 * p.Wi : p.Wi;
     SDEO_CHECK((Hv + 2 * p.pad - p.R) / p.stride + 1 == p.Ho && (Wv + 2 * p.pad - p.S) / p.stride + 1 == p.Wo,
@@ -375,7 +526,6 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
                p.Ho, p.Wo, p.R, p.S, p.stride, p.pad, p.ups);
   }
   const Plan pl = make_plan(p);
-  const TileCfg& c = kTiles[pl.tile];
   KP kp{};
   kp.x = p.x; kp.w = p.w; kp.y = p.y; kp.y32 = p.y32; kp.bias = p.bias; kp.bias2 = p.bias2; kp.res = p.res;
   kp.ws = p.workspace;
@@ -385,20 +535,21 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
   kp.ldx = p.ldx; kp.ldw = p.ldw; kp.ldy = p.ldy; kp.ldres = p.ldres; kp.ld_bias2 = p.ld_bias2;
   kp.act = p.act; kp.bias_per_row = p.bias_per_row; kp.scale = p.scale;
   kp.nk = pl.nk; kp.splitk = pl.splitk; kp.nk_per_split = cdiv(pl.nk, pl.splitk);
-  kp.tiles_m = pl.tiles_m;
+  kp.tiles_m = pl.tiles_m; kp.tiles_n = pl.tiles_n;
   if (pl.splitk > 1) {
     const size_t need = (size_t)pl.splitk * p.M * p.N * sizeof(float);
     SDEO_CHECK(p.workspace && p.workspace_bytes >= need, "conv_gemm: split-K workspace too small (%zu < %zu)",
                p.workspace_bytes, need);
   }
   const int tiles = pl.tiles_m * pl.tiles_n;
+  static bool done[kNumTiles] = {false, false, false, false, false};
   int rc = 0;
   switch (pl.tile) {
-    case 0: rc = launch<128, 128, 64, false>(kp, tiles, stream); break;
-    case 1: rc = launch<128, 64, 64, false>(kp, tiles, stream); break;
-    case 2: rc = launch<64, 64, 64, false>(kp, tiles, stream); break;
-    case 3: rc = launch<128, 64, 32, true>(kp, tiles, stream); break;
-    case 4: rc = launch<64, 64, 32, true>(kp, tiles, stream); break;
+    case 0: rc = launch_k(&conv_gemm_dma_kernel<128, 128, 3>, 3 * (128 + 128) * 128, &done[0], kp, tiles, stream); break;
+    case 1: rc = launch_k(&conv_gemm_dma_kernel<128, 64, 3>, 3 * (128 + 64) * 128, &done[1], kp, tiles, stream); break;
+    case 2: rc = launch_k(&conv_gemm_dma_kernel<64, 64, 4>, 4 * (64 + 64) * 128, &done[2], kp, tiles, stream); break;
+    case 3: rc = launch_k(&conv_gemm_kernel<128, 64, 32, true>, 2 * (128 + 64) * 64, &done[3], kp, tiles, stream); break;
+    case 4: rc = launch_k(&conv_gemm_kernel<64, 64, 32, true>, 2 * (64 + 64) * 64, &done[4], kp, tiles, stream); break;
     default: return fail("conv_gemm: bad tile %d", pl.tile);
   }
   if (rc) return rc;
@@ -407,7 +558,6 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, stream, kp);
     SDEO_HIP(hipGetLastError());
   }
-  (void)c;
   return 0;
 }
 
