@@ -42,6 +42,8 @@ typedef struct sdeo_handle_s* sdeo_handle;
 
 const char* sdeo_last_error(void);
 int sdeo_version(void);
+/* tuning hook for tools/tune_gemm.py: force tile config / split-K of the following conv/GEMM launches (-1, 0 = heuristic) */
+void sdeo_debug_force_gemm_plan(int tile, int splitk);
 
 /* ------------------------------------------------------------------ op-level entry points (used by tests)
 

@@ -30,6 +30,7 @@ extern "C" {
 
 const char* sdeo_last_error(void) { return g_last_error.c_str(); }
 int sdeo_version(void) { return 100; }
+void sdeo_debug_force_gemm_plan(int tile, int splitk) { conv_gemm_debug_force(tile, splitk); }
 
 size_t sdeo_groupnorm_workspace_bytes(int n, int hw, int groups) {
   return (size_t)n * gn_chunks(hw) * groups * 2 * sizeof(float);

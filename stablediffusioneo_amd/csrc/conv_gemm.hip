@@ -24,6 +24,9 @@
 //    fill 256 CUs when M x N is small.
 #include <stdlib.h>
 
+#include <array>
+#include <map>
+
 #include "kernels.h"
 
 namespace sdeo {
@@ -116,7 +119,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // ------------------------------------------------------------------------------------------------
 // main kernel: LDS-DMA ring, Cin % 64 == 0
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int STAGES>
+template <int BM, int BN, int STAGES, bool UPS>
 __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KP p) {
   constexpr int BK = 64, CPR = 8, RPP = 32;
   constexpr int XP = BM / RPP, WP = BN / RPP, L = XP + WP;     // DMA instructions per thread per stage
@@ -140,52 +143,84 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KP p) {
   const int chunk = tid & 7, lrow = tid >> 3;
   const int cl = chunk ^ ((lrow >> 1) & 7);        // logical k-chunk this lane fetches into its (linear) LDS slot
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // provably uniform: the DMA's LDS base stays in SGPRs
 
-  int pixbase[XP], hb[XP], wb[XP];
-  bool mvalid[XP];
-  const int Hv = p.ups ? 2 * p.Hi : p.Hi, Wv = p.ups ? 2 * p.Wi : p.Wi;
+  // Gather state, all hoisted out of the K loop (the loop body must stay MFMA-bound, not address-bound):
+  //   xrow[i]  address of this row's tap (0,0) pixel at channel chunk cl (may lie outside the tensor for border
+  //            rows: it is only dereferenced when the tap's bit in vmask[i] is set)
+  //   vmask[i] bit r*S+s = tap (r,s) of row i reads inside the image (zero padding otherwise)
+  const char* xrow[XP];
+  unsigned vmask[XP];
+  int pixbase[UPS ? XP : 1], hb[UPS ? XP : 1], wb[UPS ? XP : 1];
+  const int Hv = UPS ? 2 * p.Hi : p.Hi, Wv = UPS ? 2 * p.Wi : p.Wi;
+  const int R = p.K / (p.S * p.Cin);
 #pragma unroll
   for (int i = 0; i < XP; ++i) {
     const int m = m0 + lrow + i * RPP;
-    mvalid[i] = m < p.M;
-    const int mm = mvalid[i] ? m : 0;
+    const bool mv = m < p.M;
+    const int mm = mv ? m : 0;
     const int b = mm / p.HoWo;
     const int rem = mm - b * p.HoWo;
     const int ho = rem / p.Wo;
     const int wo = rem - ho * p.Wo;
-    pixbase[i] = b * p.Hi * p.Wi;
-    hb[i] = ho * p.stride - p.pad;
-    wb[i] = wo * p.stride - p.pad;
+    const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
+    unsigned vm = 0;
+    for (int r = 0; r < R; ++r)
+      for (int s = 0; s < p.S; ++s)
+        if (mv && h0 + r >= 0 && h0 + r < Hv && w0 + s >= 0 && w0 + s < Wv) vm |= 1u << (r * p.S + s);
+    vmask[i] = vm;
+    if (UPS) {
+      pixbase[i] = b * p.Hi * p.Wi; hb[i] = h0; wb[i] = w0;
+      xrow[i] = nullptr;
+    } else {
+      xrow[i] = reinterpret_cast<const char*>(p.x) + ((long)(b * p.Hi * p.Wi + h0 * p.Wi + w0) * p.ldx + cl * 8) * 2;
+    }
   }
-  const f16* wrow[WP];
+  const char* wptr[WP];
+  int winc[WP];
 #pragma unroll
   for (int i = 0; i < WP; ++i) {
     const int n = n0 + lrow + i * RPP;
-    wrow[i] = n < p.N ? p.w + (size_t)n * p.ldw + cl * 8 : nullptr;
+    const bool nv = n < p.N;
+    wptr[i] = nv ? reinterpret_cast<const char*>(p.w + (size_t)n * p.ldw + (size_t)kbeg * BK + cl * 8) : zero;
+    winc[i] = nv ? BK * 2 : 0;
   }
   const int tapsteps = p.Cin >> 6;
+  int st_c = kbeg % tapsteps, st_r = (kbeg / tapsteps) / p.S, st_s = (kbeg / tapsteps) % p.S;   // next K-step to issue
 
-  // issue the DMAs of K-step kt into ring slot `slot` (every lane issues exactly L of them)
-  auto issue = [&](int kt, int slot) {
-    const int tap = kt / tapsteps;
-    const int c0 = ((kt - tap * tapsteps) << 6) + cl * 8;
-    const int r = tap / p.S, s = tap - r * p.S;
-    char* xs = smem + slot * STAGE + wave * 1024;
+  // issue the DMAs of the NEXT K-step into ring slot `slot` (every lane issues exactly L of them)
+  auto issue = [&](int slot) {
+    const int tapbit = st_r * p.S + st_s;
+    char* xs = smem + slot * STAGE + wave_u * 1024;
     char* wsm = xs + XBYTES;
+    if (!UPS) {
+      const long toff = ((long)(st_r * p.Wi + st_s) * p.ldx + (st_c << 6)) * 2;
 #pragma unroll
-    for (int i = 0; i < XP; ++i) {
-      int hi = hb[i] + r, wi = wb[i] + s;
-      const bool ok = mvalid[i] && hi >= 0 && hi < Hv && wi >= 0 && wi < Wv;
-      if (p.ups) { hi >>= 1; wi >>= 1; }
-      const char* src = ok ? reinterpret_cast<const char*>(p.x + (size_t)(pixbase[i] + hi * p.Wi + wi) * p.ldx + c0) : zero;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(xs + i * 4096), 16, 0, 0);
+      for (int i = 0; i < XP; ++i) {
+        const char* src = ((vmask[i] >> tapbit) & 1) ? xrow[i] + toff : zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(xs + i * 4096), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < XP; ++i) {
+        const int hi = (hb[i] + st_r) >> 1, wi = (wb[i] + st_s) >> 1;
+        const char* src = ((vmask[i] >> tapbit) & 1)
+                              ? reinterpret_cast<const char*>(p.x) + ((long)(pixbase[i] + hi * p.Wi + wi) * p.ldx + (st_c << 6) + cl * 8) * 2
+                              : zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(xs + i * 4096), 16, 0, 0);
+      }
     }
 #pragma unroll
     for (int i = 0; i < WP; ++i) {
-      const char* src = wrow[i] ? reinterpret_cast<const char*>(wrow[i] + (size_t)kt * BK) : zero;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wptr[i],
                                        (__attribute__((address_space(3))) void*)(wsm + i * 4096), 16, 0, 0);
+      wptr[i] += winc[i];
+    }
+    if (++st_c == tapsteps) {
+      st_c = 0;
+      if (++st_s == p.S) { st_s = 0; ++st_r; }
     }
   };
 
@@ -199,7 +234,7 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KP p) {
   if (nk > 0) {
 #pragma unroll
     for (int s = 0; s < PF; ++s)
-      if (s < nk) issue(kbeg + s, s);
+      if (s < nk) issue(s);
     for (int it = 0; it < nk; ++it) {
       // retire the DMAs of K-step `it`: all but the (newer) steps still allowed in flight
       const int ahead = min(PF - 1, nk - 1 - it);
@@ -207,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KP p) {
       else if (ahead == 1) wait_vmcnt<L>();
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();      // step `it` visible to every wave; everyone is done reading slot (it-1)%STAGES
-      if (it + PF < nk) issue(kbeg + it + PF, (it + PF) % STAGES);
+      if (it + PF < nk) issue((it + PF) % STAGES);
       const char* xs = smem + (it % STAGES) * STAGE;
       const char* wsm = xs + XBYTES;
 #pragma unroll
@@ -433,24 +468,37 @@ static const TileCfg kTiles[] = {
     {64, 64, 64, 4, TK_DMA, 0.65f, 2, "conv_gemm_dma_kernel<64,64,4>"},
     {128, 64, 32, 2, TK_GENERIC, 0.85f, 3, "conv_gemm_kernel<128,64,32,true>"},
     {64, 64, 32, 2, TK_GENERIC, 0.65f, 4, "conv_gemm_kernel<64,64,32,true>"},
+    {256, 128, 64, 3, TK_DMA, 1.25f, 1, "conv_gemm_dma_kernel<256,128,3>"},
 };
-static const int kNumTiles = 5;
+static const int kNumTiles = 6;
 static const int kNumCU = 256;
 
 struct Plan { int tile; int splitk; int nk; int tiles_m, tiles_n; };
 
 static bool is_fast(const ConvGemm& p) { return p.Cin % 64 == 0; }
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
+// tuning hook (tools/tune_gemm.py): force the tile configuration / split-K factor of every following launch
+static int g_force_tile = -1, g_force_splitk = 0;
+void conv_gemm_debug_force(int tile, int splitk) { g_force_tile = tile; g_force_splitk = splitk; }
+
+// plans measured on this device by conv_gemm_autotune (shape -> tile, split-K); consulted before the heuristic
+typedef std::array<int, 10> ShapeKey;
+static std::map<ShapeKey, std::pair<int, int>> g_tuned;
+static ShapeKey key_of(const ConvGemm& p) { return {p.M, p.N, p.K, p.Cin, p.R, p.stride, p.ups, p.Hi, p.Wi, p.B}; }
 
 static Plan make_plan(const ConvGemm& p) {
   Plan best{};
   const bool fast = is_fast(p);
-  const int force_tile = p.force_tile >= 0 ? p.force_tile : env_int("SDEO_FORCE_TILE", -1);
-  const int force_sk = p.force_splitk > 0 ? p.force_splitk : env_int("SDEO_FORCE_SPLITK", 0);
+  const int force_tile = p.force_tile >= 0 ? p.force_tile : g_force_tile;
+  const int force_sk = p.force_splitk > 0 ? p.force_splitk : g_force_splitk;
+  if (force_tile < 0 && force_sk <= 0 && fast) {
+    auto it = g_tuned.find(key_of(p));
+    if (it != g_tuned.end()) {
+      const TileCfg& c = kTiles[it->second.first];
+      const int nk = cdiv(p.K, c.bk);
+      return Plan{it->second.first, it->second.second, nk, cdiv(p.M, c.bm), cdiv(p.N, c.bn)};
+    }
+  }
   float best_t = 1e30f;
   for (int t = 0; t < kNumTiles; ++t) {
     const TileCfg& c = kTiles[t];
@@ -542,14 +590,27 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
                p.workspace_bytes, need);
   }
   const int tiles = pl.tiles_m * pl.tiles_n;
-  static bool done[kNumTiles] = {false, false, false, false, false};
+  static bool done[10] = {false, false, false, false, false, false, false, false, false, false};
   int rc = 0;
   switch (pl.tile) {
-    case 0: rc = launch_k(&conv_gemm_dma_kernel<128, 128, 3>, 3 * (128 + 128) * 128, &done[0], kp, tiles, stream); break;
-    case 1: rc = launch_k(&conv_gemm_dma_kernel<128, 64, 3>, 3 * (128 + 64) * 128, &done[1], kp, tiles, stream); break;
-    case 2: rc = launch_k(&conv_gemm_dma_kernel<64, 64, 4>, 4 * (64 + 64) * 128, &done[2], kp, tiles, stream); break;
+    case 0:
+      rc = p.ups ? launch_k(&conv_gemm_dma_kernel<128, 128, 3, true>, 3 * (128 + 128) * 128, &done[6], kp, tiles, stream)
+                 : launch_k(&conv_gemm_dma_kernel<128, 128, 3, false>, 3 * (128 + 128) * 128, &done[0], kp, tiles, stream);
+      break;
+    case 1:
+      rc = p.ups ? launch_k(&conv_gemm_dma_kernel<128, 64, 3, true>, 3 * (128 + 64) * 128, &done[7], kp, tiles, stream)
+                 : launch_k(&conv_gemm_dma_kernel<128, 64, 3, false>, 3 * (128 + 64) * 128, &done[1], kp, tiles, stream);
+      break;
+    case 2:
+      rc = p.ups ? launch_k(&conv_gemm_dma_kernel<64, 64, 4, true>, 4 * (64 + 64) * 128, &done[8], kp, tiles, stream)
+                 : launch_k(&conv_gemm_dma_kernel<64, 64, 4, false>, 4 * (64 + 64) * 128, &done[2], kp, tiles, stream);
+      break;
     case 3: rc = launch_k(&conv_gemm_kernel<128, 64, 32, true>, 2 * (128 + 64) * 64, &done[3], kp, tiles, stream); break;
     case 4: rc = launch_k(&conv_gemm_kernel<64, 64, 32, true>, 2 * (64 + 64) * 64, &done[4], kp, tiles, stream); break;
+    case 5:
+      rc = p.ups ? launch_k(&conv_gemm_dma_kernel<256, 128, 3, true>, 3 * (256 + 128) * 128, &done[9], kp, tiles, stream)
+                 : launch_k(&conv_gemm_dma_kernel<256, 128, 3, false>, 3 * (256 + 128) * 128, &done[5], kp, tiles, stream);
+      break;
     default: return fail("conv_gemm: bad tile %d", pl.tile);
   }
   if (rc) return rc;
@@ -558,6 +619,60 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, stream, kp);
     SDEO_HIP(hipGetLastError());
   }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// autotune: measure every (tile, split-K) candidate for one problem on the device and remember the fastest.
+// Called once per distinct shape from sdeo_configure (never on the hot path, never under graph capture).
+// ------------------------------------------------------------------------------------------------
+static const size_t kTuneWorkspaceCap = (size_t)256 << 20;
+
+size_t conv_gemm_autotune_workspace_bytes(const ConvGemm& p) {
+  if (!is_fast(p)) return conv_gemm_workspace_bytes(p);
+  const size_t per = (size_t)p.M * p.N * sizeof(float);
+  size_t want = per * 16;
+  if (want > kTuneWorkspaceCap) want = kTuneWorkspaceCap / per * per;
+  const size_t heur = conv_gemm_workspace_bytes(p);
+  return want > heur ? want : heur;
+}
+
+int conv_gemm_autotune(const ConvGemm& p, hipStream_t stream) {
+  if (!is_fast(p) || g_force_tile >= 0 || g_force_splitk > 0) return 0;
+  const ShapeKey key = key_of(p);
+  if (g_tuned.count(key)) return 0;
+  static const int tiles[] = {0, 1, 2, 5};
+  static const int sks[] = {1, 2, 3, 4, 6, 8, 12, 16};
+  hipEvent_t a, b;
+  SDEO_HIP(hipEventCreate(&a));
+  SDEO_HIP(hipEventCreate(&b));
+  float best = 1e30f;
+  std::pair<int, int> pick(-1, 1);
+  for (int t : tiles) {
+    const int nk = cdiv(p.K, kTiles[t].bk);
+    const int wgs1 = cdiv(p.M, kTiles[t].bm) * cdiv(p.N, kTiles[t].bn);
+    for (int sk : sks) {
+      if (sk > 1 && (nk / sk < 4 || (size_t)sk * p.M * p.N * sizeof(float) > p.workspace_bytes || !p.workspace)) continue;
+      if (sk > 1 && wgs1 >= 4 * kNumCU) continue;      // already several rounds of workgroups: splitting K only adds traffic
+      ConvGemm q = p;
+      q.force_tile = t;
+      q.force_splitk = sk;
+      if (int rc = conv_gemm(q, stream)) return rc;    // warm-up (also sets the function attributes)
+      SDEO_HIP(hipEventRecord(a, stream));
+      const int reps = 3;
+      for (int r = 0; r < reps; ++r)
+        if (int rc = conv_gemm(q, stream)) return rc;
+      SDEO_HIP(hipEventRecord(b, stream));
+      SDEO_HIP(hipEventSynchronize(b));
+      float ms = 0.f;
+      SDEO_HIP(hipEventElapsedTime(&ms, a, b));
+      ms /= reps;
+      if (ms < best) { best = ms; pick = {t, make_plan(q).splitk}; }
+    }
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  if (pick.first >= 0) g_tuned[key] = pick;
   return 0;
 }
 

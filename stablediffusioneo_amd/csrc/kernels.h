@@ -37,6 +37,10 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream);
 size_t conv_gemm_workspace_bytes(const ConvGemm& p);
 // name of the kernel instantiation the launcher will pick (for profiles; matches the rocprof kernel name's template args)
 const char* conv_gemm_kernel_name(const ConvGemm& p);
+void conv_gemm_debug_force(int tile, int splitk);
+// one-time on-device plan search for p's shape (p needs valid scratch pointers); workspace to reserve for it
+int conv_gemm_autotune(const ConvGemm& p, hipStream_t stream);
+size_t conv_gemm_autotune_workspace_bytes(const ConvGemm& p);   // tuning hook: -1 / 0 restore the heuristic
 
 // ------------------------------------------------------------------------------------------
 // GroupNorm (NHWC fp16, fp32 statistics, eps honoured) + optional SiLU; two launches:

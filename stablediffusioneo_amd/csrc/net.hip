@@ -237,6 +237,7 @@ struct sdeo_handle_s {
   std::vector<size_t> ctrl_elems;
   size_t device_bytes = 0;
   // profiling (sdeo_profile_*): HIP events around every launch of the next programs
+  bool autotune = true;     // measure GEMM plans per shape at configure time (SDEO_AUTOTUNE=0 disables)
   bool profiling = false;
   std::vector<ProfRec> prof;
   std::string prof_report;
@@ -464,7 +465,16 @@ struct Builder {
 
 
   void launch_conv(ConvGemm p, const float* scale_host) {
-    max_splitk = std::max(max_splitk, conv_gemm_workspace_bytes(p));
+    max_splitk = std::max(max_splitk, e->autotune ? conv_gemm_autotune_workspace_bytes(p) : conv_gemm_workspace_bytes(p));
+    if (!dry && e->autotune) {
+      ConvGemm q = p;
+      q.workspace = e->splitk_ws;
+      q.workspace_bytes = e->splitk_ws_bytes;
+      if (conv_gemm_autotune(q, 0) && err.empty()) err = std::string("autotune failed: ") + sdeo_last_error();
+    }
+    if (!dry && getenv("SDEO_DUMP_GEMM"))   // shape census for tools/tune_gemm.py
+      fprintf(stderr, "SDEO_GEMM %d %d %d %d %d %d %d %d %d %d %s\n", p.M, p.N, p.K, p.Cin, p.R, p.stride, p.ups, p.B, p.Hi, p.Wi,
+              conv_gemm_kernel_name(p));
     Engine* eng = e;
     push([p, scale_host, eng](hipStream_t s) mutable {
       p.workspace = eng->splitk_ws;
@@ -1061,6 +1071,7 @@ int sdeo_create(const sdeo_config* cfg, sdeo_handle* out) {
   e->cplan = make_uplan(*cfg, false);
   SDEO_CHECK(e->cplan.in.size() + 1 <= 13, "sdeo_create: more than 13 control tensors");
   e->hconvs = hint_convs(*cfg);
+  if (const char* at = getenv("SDEO_AUTOTUNE")) e->autotune = atoi(at) != 0;
   for (int i = 0; i < 13; ++i) e->scales[i] = 1.0f;
   build_registry(e.get());
   SDEO_HIP(hipMalloc((void**)&e->wslab, e->wslab_bytes));

@@ -49,7 +49,22 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
   for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
   if (prow < P) {
     const f16* base = x + ((size_t)b * HW) * ldx + c0;
-    for (int pix = pbeg + prow; pix < pend; pix += P) {
+    // 4 independent 16-byte loads in flight per thread (the loop is latency-bound otherwise)
+    int pix = pbeg + prow;
+    for (; pix + 3 * P < pend; pix += 4 * P) {
+      f16x8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(base + (size_t)(pix + u * P) * ldx);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = (float)v[u][j];
+          s[j] += f;
+          q[j] += f * f;
+        }
+    }
+    for (; pix < pend; pix += P) {
       const f16x8 v = *reinterpret_cast<const f16x8*>(base + (size_t)pix * ldx);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -84,7 +99,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
 __global__ __launch_bounds__(256) void gn_apply_kernel(f16* __restrict__ y, int ldy, const f16* __restrict__ x, int ldx,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int HW, int C, int cpg, int nvb, const float* __restrict__ partials,
-                                                       int nchunks, int groups, float eps, int with_silu, int ppc) {
+                                                       int nchunks, int groups, float eps, int with_silu, int ppc, int nsc) {
   __shared__ float s_a[256 * 8];
   __shared__ float s_b[256 * 8];
   __shared__ float s_mean[64];
@@ -100,8 +115,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(f16* __restrict__ y, int 
     const int gl = tid / tpg, l = tid - gl * tpg;
     float ts = 0.f, tq = 0.f;
     if (gl < gpb) {
-      const float* src = partials + ((size_t)b * nchunks * groups + part * gpb + gl) * 2;
-      for (int c = l; c < nchunks; c += tpg) {
+      const float* src = partials + ((size_t)b * nsc * groups + part * gpb + gl) * 2;
+      for (int c = l; c < nsc; c += tpg) {
         ts += src[(size_t)c * groups * 2];
         tq += src[(size_t)c * groups * 2 + 1];
       }
@@ -139,7 +154,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(f16* __restrict__ y, int 
   const int pend = min(HW, pbeg + ppc);
   const f16* xb = x + ((size_t)b * HW) * ldx + c0;
   f16* yb = y + ((size_t)b * HW) * ldy + c0;
-  for (int pix = pbeg + prow; pix < pend; pix += P) {
+  int pix = pbeg + prow;
+  for (; pix + 3 * P < pend; pix += 4 * P) {
+    f16x8 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(xb + (size_t)(pix + u * P) * ldx);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      f16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f = (float)v[u][j] * a[j] + bb[j];
+        if (with_silu) f = silu_f(f);
+        o[j] = (f16)f;
+      }
+      *reinterpret_cast<f16x8*>(yb + (size_t)(pix + u * P) * ldy) = o;
+    }
+  }
+  for (; pix < pend; pix += P) {
     const f16x8 v = *reinterpret_cast<const f16x8*>(xb + (size_t)pix * ldx);
     f16x8 o;
 #pragma unroll
@@ -165,9 +197,15 @@ int groupnorm_nhwc(f16* y, int ldy, const f16* x, int ldx, const float* gamma, c
   const int chunks = gn_chunks(HW);
   const int ppc = cdiv(HW, chunks);
   dim3 grid(chunks, parts, B);
-  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, stream, x, ldx, HW, C, cpg, nvb, partials, chunks, groups, ppc);
+  // statistics use coarser chunks (~64 KB of activations each, at most 128): every apply block re-reduces all of them
+  int sc = (int)(((size_t)HW * C * 2) >> 16);
+  sc = sc < 1 ? 1 : (sc > 128 ? 128 : sc);
+  if (sc > chunks) sc = chunks;
+  const int sppc = cdiv(HW, sc);
+  dim3 sgrid(sc, parts, B);
+  hipLaunchKernelGGL(gn_stats_kernel, sgrid, dim3(256), 0, stream, x, ldx, HW, C, cpg, nvb, partials, sc, groups, sppc);
   hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, stream, y, ldy, x, ldx, gamma, beta, HW, C, cpg, nvb, partials,
-                     chunks, groups, eps, with_silu, ppc);
+                     chunks, groups, eps, with_silu, ppc, sc);
   SDEO_HIP(hipGetLastError());
   return 0;
 }
