@@ -44,6 +44,8 @@ const char* sdeo_last_error(void);
 int sdeo_version(void);
 /* tuning hook for tools/tune_gemm.py: force tile config / split-K of the following conv/GEMM launches (-1, 0 = heuristic) */
 void sdeo_debug_force_gemm_plan(int tile, int splitk);
+/* y = silu(x) on n fp16 elements: launch-floor probe for tools/launch_floor.py */
+int sdeo_debug_silu(void* y, const void* x, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------ op-level entry points (used by tests)
 

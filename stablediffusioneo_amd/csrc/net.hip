@@ -220,6 +220,15 @@ struct sdeo_handle_s {
   size_t splitk_ws_bytes = 0;
   float* gn_ws = nullptr;
   size_t gn_ws_bytes = 0;
+  // second arena + workspaces + stream: ControlNet runs concurrently with the UNet encoder (both depend only on
+  // x, t, context), joined before the decoder consumes the controls
+  char* arena2 = nullptr;
+  size_t arena2_bytes = 0;
+  float* splitk_ws2 = nullptr;
+  float* gn_ws2 = nullptr;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool overlap = true;       // SDEO_OVERLAP=0 runs ControlNet and UNet back to back on one stream
   // boundary buffers (device, owned)
   float* in_x = nullptr; float* in_hint = nullptr; float* in_ctx = nullptr; int64_t* in_t = nullptr;
   float* in_ctrl[13] = {nullptr};
@@ -233,7 +242,7 @@ struct sdeo_handle_s {
   int only_mid = 0;
   bool use_control = true;
   // programs
-  Program p_hint, p_ctx_cn, p_ctx_unet, p_cn, p_cn_export, p_ctrl_import, p_unet_ctrl, p_unet_noctrl, p_vae;
+  Program p_hint, p_ctx_cn, p_ctx_unet, p_cn, p_cn_export, p_ctrl_import, p_unet_enc, p_unet_dec, p_unet_noctrl, p_vae;
   std::vector<size_t> ctrl_elems;
   size_t device_bytes = 0;
   // profiling (sdeo_profile_*): HIP events around every launch of the next programs
@@ -432,6 +441,8 @@ struct Builder {
   Engine* e;
   Arena* arena;
   bool dry;
+  char* base = nullptr;      // device base of `arena`
+  int ws_sel = 0;            // 0: main-stream workspaces, 1: side-stream (ControlNet) workspaces
   Program* prog = nullptr;
   size_t max_splitk = 0, max_gn = 0;
   std::string err;
@@ -440,7 +451,7 @@ struct Builder {
     T t;
     t.n = n; t.h = h; t.w = w; t.c = c; t.ld = c;
     t.off = arena->alloc((size_t)n * h * w * c * 2);
-    t.p = reinterpret_cast<f16*>(e->arena + t.off);
+    t.p = reinterpret_cast<f16*>(base + t.off);
     return t;
   }
   T alloc2d(int rows, int c) { return alloc(1, 1, rows, c); }
@@ -468,7 +479,7 @@ struct Builder {
     max_splitk = std::max(max_splitk, e->autotune ? conv_gemm_autotune_workspace_bytes(p) : conv_gemm_workspace_bytes(p));
     if (!dry && e->autotune) {
       ConvGemm q = p;
-      q.workspace = e->splitk_ws;
+      q.workspace = ws_sel ? e->splitk_ws2 : e->splitk_ws;
       q.workspace_bytes = e->splitk_ws_bytes;
       if (conv_gemm_autotune(q, 0) && err.empty()) err = std::string("autotune failed: ") + sdeo_last_error();
     }
@@ -476,8 +487,9 @@ struct Builder {
       fprintf(stderr, "SDEO_GEMM %d %d %d %d %d %d %d %d %d %d %s\n", p.M, p.N, p.K, p.Cin, p.R, p.stride, p.ups, p.B, p.Hi, p.Wi,
               conv_gemm_kernel_name(p));
     Engine* eng = e;
-    push([p, scale_host, eng](hipStream_t s) mutable {
-      p.workspace = eng->splitk_ws;
+    const int sel = ws_sel;
+    push([p, scale_host, eng, sel](hipStream_t s) mutable {
+      p.workspace = sel ? eng->splitk_ws2 : eng->splitk_ws;
       p.workspace_bytes = eng->splitk_ws_bytes;
       if (scale_host) p.scale = *scale_host;
       return conv_gemm(p, s);
@@ -542,8 +554,9 @@ struct Builder {
     const int B = x.n, HW = x.h * x.w, C = x.c;
     max_gn = std::max(max_gn, (size_t)B * gn_chunks(HW) * 32 * 2 * sizeof(float));
     Engine* eng = e;
+    const int sel = ws_sel;
     const f16* xp = x.p; f16* yp = y.p; const int ldx = x.ld, ldy = y.ld;
-    push([=](hipStream_t s) { return groupnorm_nhwc(yp, ldy, xp, ldx, g, b, B, HW, C, 32, eps, silu_, eng->gn_ws, s); }, "groupnorm", 0,
+    push([=](hipStream_t s) { return groupnorm_nhwc(yp, ldy, xp, ldx, g, b, B, HW, C, 32, eps, silu_, sel ? eng->gn_ws2 : eng->gn_ws, s); }, "groupnorm", 0,
          3.0 * 2.0 * B * HW * C);
     if (out) y.off = (size_t)-1;
     return y;
@@ -722,10 +735,11 @@ static int run(Engine* e, const Program& p, hipStream_t s) {
   return 0;
 }
 
-static void build_all(Engine* e, Arena& arena, bool dry, size_t* max_splitk, size_t* max_gn, std::string* err) {
+static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* max_splitk, size_t* max_gn, std::string* err) {
   const sdeo_config& c = e->cfg;
   const int N = e->N, h = e->lh, w = e->lw;
   Builder b{e, &arena, dry};
+  b.base = e->arena;
   Built bt;
   const int TkS = round8(c.context_len);
 
@@ -813,6 +827,7 @@ static void build_all(Engine* e, Arena& arena, bool dry, size_t* max_splitk, siz
   // ---- ControlNet program (`cldm/cldm.py:284-305`)
   {
     b.prog = &e->p_cn;
+    b.arena = &arena2; b.base = e->arena2; b.ws_sel = 1;
     const std::string ns = NS_CN;
     float* emb_all = build_time_embed(b, ns, 1, N);
     T x0 = b.alloc(N, h, w, round8(c.in_channels));
@@ -839,6 +854,7 @@ static void build_all(Engine* e, Arena& arena, bool dry, size_t* max_splitk, siz
     Builder::CO zo; zo.out = &e->ctrl[e->cplan.in.size()];
     b.conv(m, ns + "middle_block_out.0", e->cplan.in_ch.back(), 1, 1, 0, zo);
     b.release(m);
+    b.arena = &arena; b.base = e->arena; b.ws_sel = 0;
   }
   const int nctrl = (int)e->cplan.in.size() + 1;
 
@@ -860,7 +876,7 @@ static void build_all(Engine* e, Arena& arena, bool dry, size_t* max_splitk, siz
   // ---- UNet programs (`cldm/cldm.py:22-45`), with and without control
   for (int variant = 0; variant < 2; ++variant) {
     const bool with_ctrl = variant == 0;
-    b.prog = with_ctrl ? &e->p_unet_ctrl : &e->p_unet_noctrl;
+    b.prog = with_ctrl ? &e->p_unet_enc : &e->p_unet_noctrl;
     const std::string ns = NS_UNET;
     float* emb_all = build_time_embed(b, ns, 0, N);
     T x0 = b.alloc(N, h, w, round8(c.in_channels));
@@ -884,6 +900,7 @@ static void build_all(Engine* e, Arena& arena, bool dry, size_t* max_splitk, siz
     T view = cat; view.c = e->uplan.mid.back().cout; view.off = (size_t)-1;
     T m = run_blocks(ns, e->uplan.mid, hcur, false, emb_all, e->emb_total[0], 0, &view);
     (void)m;
+    if (with_ctrl) b.prog = &e->p_unet_dec;     // everything below needs the controls: runs after the join
     if (with_ctrl) {   // h += control.pop()
       f16* yp = view.p; const int ld = view.ld, rows = view.rows(), Cc = view.c;
       const f16* cp = e->ctrl[ci].p; const int ldc = e->ctrl[ci].ld; const float* sc = &e->scales[ci];
@@ -1044,8 +1061,10 @@ static void free_configured(Engine* e) {
   e->extra_allocs.clear();
   if (e->arena) (void)hipFree(e->arena);
   e->arena = nullptr;
-  for (Program* p : {&e->p_hint, &e->p_ctx_cn, &e->p_ctx_unet, &e->p_cn, &e->p_cn_export, &e->p_ctrl_import, &e->p_unet_ctrl,
-                     &e->p_unet_noctrl, &e->p_vae})
+  if (e->arena2) (void)hipFree(e->arena2);
+  e->arena2 = nullptr;
+  for (Program* p : {&e->p_hint, &e->p_ctx_cn, &e->p_ctx_unet, &e->p_cn, &e->p_cn_export, &e->p_ctrl_import, &e->p_unet_enc,
+                     &e->p_unet_dec, &e->p_unet_noctrl, &e->p_vae})
     p->clear();
 }
 
@@ -1072,6 +1091,10 @@ int sdeo_create(const sdeo_config* cfg, sdeo_handle* out) {
   SDEO_CHECK(e->cplan.in.size() + 1 <= 13, "sdeo_create: more than 13 control tensors");
   e->hconvs = hint_convs(*cfg);
   if (const char* at = getenv("SDEO_AUTOTUNE")) e->autotune = atoi(at) != 0;
+  if (const char* ov = getenv("SDEO_OVERLAP")) e->overlap = atoi(ov) != 0;
+  SDEO_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+  SDEO_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  SDEO_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
   for (int i = 0; i < 13; ++i) e->scales[i] = 1.0f;
   build_registry(e.get());
   SDEO_HIP(hipMalloc((void**)&e->wslab, e->wslab_bytes));
@@ -1092,6 +1115,9 @@ int sdeo_create(const sdeo_config* cfg, sdeo_handle* out) {
 int sdeo_destroy(sdeo_handle h) {
   if (!h) return 0;
   free_configured(h);
+  if (h->side) (void)hipStreamDestroy(h->side);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->wslab) (void)hipFree(h->wslab);
   if (h->stage) (void)hipFree(h->stage);
   delete h;
@@ -1190,24 +1216,31 @@ int sdeo_configure(sdeo_handle h, int n, int latent_h, int latent_w) {
   size_t ms = 0, mg = 0;
   std::string err;
   {
-    Arena a;
-    build_all(h, a, true, &ms, &mg, &err);
+    Arena a, a2;
+    build_all(h, a, a2, true, &ms, &mg, &err);
     SDEO_CHECK(err.empty(), "sdeo_configure: %s", err.c_str());
     h->arena_bytes = align_up(a.peak, 256);
+    h->arena2_bytes = align_up(a2.peak, 256);
   }
   SDEO_HIP(hipMalloc((void**)&h->arena, h->arena_bytes));
   SDEO_HIP(hipMemset(h->arena, 0, h->arena_bytes));
-  h->device_bytes += h->arena_bytes;
+  SDEO_HIP(hipMalloc((void**)&h->arena2, h->arena2_bytes));
+  SDEO_HIP(hipMemset(h->arena2, 0, h->arena2_bytes));
+  h->device_bytes += h->arena_bytes + h->arena2_bytes;
   if (int rc = dev_alloc(h, &h->splitk_ws, ms)) return rc;
+  if (int rc = dev_alloc(h, &h->splitk_ws2, ms)) return rc;
   h->splitk_ws_bytes = ms;
   if (int rc = dev_alloc(h, &h->gn_ws, mg)) return rc;
+  if (int rc = dev_alloc(h, &h->gn_ws2, mg)) return rc;
   h->gn_ws_bytes = mg;
   {
-    Arena a;
-    build_all(h, a, false, &ms, &mg, &err);
+    Arena a, a2;
+    build_all(h, a, a2, false, &ms, &mg, &err);
     SDEO_CHECK(err.empty(), "sdeo_configure: %s", err.c_str());
-    SDEO_CHECK(align_up(a.peak, 256) == h->arena_bytes, "sdeo_configure: arena plan not reproducible");
+    SDEO_CHECK(align_up(a.peak, 256) == h->arena_bytes && align_up(a2.peak, 256) == h->arena2_bytes,
+               "sdeo_configure: arena plan not reproducible");
   }
+  SDEO_HIP(hipDeviceSynchronize());      // autotune launches are done before the first real forward
   return 0;
 }
 
@@ -1273,7 +1306,8 @@ int sdeo_unet_forward(sdeo_handle h, const float* x_noisy, const int64_t* timest
       if (int rc = copy_in(h->in_ctrl[i], controls[i], h->ctrl_elems[i] * 4, s)) return rc;
     }
     if (int rc = run(h, h->p_ctrl_import, s)) return rc;
-    if (int rc = run(h, h->p_unet_ctrl, s)) return rc;
+    if (int rc = run(h, h->p_unet_enc, s)) return rc;
+    if (int rc = run(h, h->p_unet_dec, s)) return rc;
   } else {
     if (int rc = run(h, h->p_unet_noctrl, s)) return rc;
   }
@@ -1296,8 +1330,19 @@ int sdeo_apply_model(sdeo_handle h, const float* x_noisy, const float* hint, con
   if (no_control) {
     if (int rc = run(h, h->p_unet_noctrl, s)) return rc;
   } else {
-    if (int rc = run(h, h->p_cn, s)) return rc;
-    if (int rc = run(h, h->p_unet_ctrl, s)) return rc;
+    if (h->overlap && !h->profiling) {
+      // fork: ControlNet on the side stream, UNet encoder + middle block on the caller's stream (capturable)
+      SDEO_HIP(hipEventRecord(h->ev_fork, s));
+      SDEO_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+      if (int rc = run(h, h->p_cn, h->side)) return rc;
+      SDEO_HIP(hipEventRecord(h->ev_join, h->side));
+      if (int rc = run(h, h->p_unet_enc, s)) return rc;
+      SDEO_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+    } else {
+      if (int rc = run(h, h->p_cn, s)) return rc;
+      if (int rc = run(h, h->p_unet_enc, s)) return rc;
+    }
+    if (int rc = run(h, h->p_unet_dec, s)) return rc;
   }
   return copy_in(eps, h->out_eps, (size_t)h->N * h->cfg.out_channels * h->lh * h->lw * 4, s);
 }

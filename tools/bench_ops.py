@@ -6,16 +6,19 @@ from stablediffusioneo_amd import ops
 
 dev = "cuda"
 
-def timeit(fn, iters=20, warm=3):
+def timeit(fn, iters=10, warm=2):
+    """device time per call in us: replay of a hipGraph holding `iters` calls (no host launch overhead)"""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay(); torch.cuda.synchronize()
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
-        fn()
-    e.record(); torch.cuda.synchronize()
-    return s.elapsed_time(e) / iters * 1e3   # us
+    s.record(); g.replay(); g.replay(); e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / (2 * iters) * 1e3   # us
 
 def rnd(*shape, scale=1.0):
     return (torch.randn(*shape, device=dev) * scale).half()
