@@ -62,7 +62,8 @@ __device__ __forceinline__ int swz_chunk(int row, int chunk) {
 
 // ---- epilogue shared by both kernels: lane holds n = nb + fq*4 + {0..3} (4 consecutive channels) of pixel m
 template <int NI, int MI, int TM, int TN>
-__device__ __forceinline__ void epilogue(const KP& p, f32x4 (&acc)[NI][MI], int m0, int n0, int wm, int wn, int frow, int fq, int z) {
+__device__ __forceinline__ void epilogue(const KP& p, f32x4 (&acc)[NI][MI], int m0, int n0, int wm, int wn, int frow, int fq, int z,
+                                         const f32x4* bpre = nullptr) {
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
     const int m = m0 + wm * TM + j * 16 + frow;
@@ -79,6 +80,7 @@ __device__ __forceinline__ void epilogue(const KP& p, f32x4 (&acc)[NI][MI], int 
       }
       if (p.bias) {
         if (p.bias_per_row) v += p.bias[m];
+        else if (bpre) v += bpre[i];
         else v += *reinterpret_cast<const f32x4*>(p.bias + n);
       }
       if (p.bias2) v += *reinterpret_cast<const f32x4*>(p.bias2 + (size_t)b * p.ld_bias2 + n);
@@ -154,20 +156,27 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KP p) {
   int pixbase[UPS ? XP : 1], hb[UPS ? XP : 1], wb[UPS ? XP : 1];
   const int Hv = UPS ? 2 * p.Hi : p.Hi, Wv = UPS ? 2 * p.Wi : p.Wi;
   const int R = p.K / (p.S * p.Cin);
+  const bool linear = !UPS && p.K == p.Cin && p.stride == 1 && p.pad == 0;   // Linear / conv1x1: row m IS pixel m
 #pragma unroll
   for (int i = 0; i < XP; ++i) {
     const int m = m0 + lrow + i * RPP;
     const bool mv = m < p.M;
+    if (linear) {
+      vmask[i] = mv ? 1u : 0u;
+      xrow[i] = reinterpret_cast<const char*>(p.x) + ((long)m * p.ldx + cl * 8) * 2;
+      continue;
+    }
     const int mm = mv ? m : 0;
     const int b = mm / p.HoWo;
     const int rem = mm - b * p.HoWo;
     const int ho = rem / p.Wo;
     const int wo = rem - ho * p.Wo;
     const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
+    // taps inside the image: rows rlo..rhi-1, columns slo..shi-1
+    const int rlo = max(0, -h0), rhi = min(R, Hv - h0), slo = max(0, -w0), shi = min(p.S, Wv - w0);
+    const unsigned sm = (mv && shi > slo) ? (((1u << shi) - 1u) & ~((1u << slo) - 1u)) : 0u;
     unsigned vm = 0;
-    for (int r = 0; r < R; ++r)
-      for (int s = 0; s < p.S; ++s)
-        if (mv && h0 + r >= 0 && h0 + r < Hv && w0 + s >= 0 && w0 + s < Wv) vm |= 1u << (r * p.S + s);
+    for (int r = rlo; r < rhi; ++r) vm |= sm << (r * p.S);
     vmask[i] = vm;
     if (UPS) {
       pixbase[i] = b * p.Hi * p.Wi; hb[i] = h0; wb[i] = w0;
@@ -231,6 +240,16 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KP p) {
     for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int frow = lane & 15, fq = lane >> 4;
 
+  // the bias is needed only by the epilogue: fetch it now (issued before, hence older than, every DMA) so the
+  // epilogue does not start with a dependent global round trip
+  f32x4 bpre[NI];
+  const bool use_bpre = p.bias && !p.bias_per_row && p.splitk == 1;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int n = n0 + wn * TN + i * 16 + fq * 4;
+    bpre[i] = (use_bpre && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
   if (nk > 0) {
 #pragma unroll
     for (int s = 0; s < PF; ++s)
@@ -266,7 +285,7 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KP p) {
       }
     }
   }
-  epilogue<NI, MI, TM, TN>(p, acc, m0, n0, wm, wn, frow, fq, z);
+  epilogue<NI, MI, TM, TN>(p, acc, m0, n0, wm, wn, frow, fq, z, use_bpre ? bpre : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -109,16 +109,37 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(f16* __restrict__ y, int 
   const int cv = tid % nvb, prow = tid / nvb;
   const int chunk = blockIdx.x, part = blockIdx.y, b = blockIdx.z;
   const int gpb = nvb * 8 / cpg;
+  const bool active = prow < P;
+  const int c0 = (part * nvb + cv) * 8;
+  const int pbeg = chunk * ppc;
+  const int pend = min(HW, pbeg + ppc);
+  const f16* xb = x + ((size_t)b * HW) * ldx + c0;
+  f16* yb = y + ((size_t)b * HW) * ldy + c0;
+  // The kernel is a chain of dependent round trips (partials -> mean/rstd -> gamma/beta -> x -> y) on tensors of a
+  // few MB, i.e. latency-bound: issue every load that does not depend on the statistics FIRST.
+  f16x8 xv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int pix = pbeg + prow + u * P;
+    if (active && pix < pend) xv[u] = *reinterpret_cast<const f16x8*>(xb + (size_t)pix * ldx);
+  }
+  float gpre[8], bpre[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = tid + k * 256;
+    if (c < nvb * 8) { gpre[k] = gamma[part * nvb * 8 + c]; bpre[k] = beta[part * nvb * 8 + c]; }
+  }
   {
-    // second-level reduction over chunks: tpg threads per group, fixed order => deterministic
+    // second-level reduction over the statistics chunks: tpg threads per group, fixed order => deterministic
     const int tpg = 256 / gpb;
     const int gl = tid / tpg, l = tid - gl * tpg;
     float ts = 0.f, tq = 0.f;
     if (gl < gpb) {
-      const float* src = partials + ((size_t)b * nsc * groups + part * gpb + gl) * 2;
+      const float2* src = reinterpret_cast<const float2*>(partials) + ((size_t)b * nsc * groups + part * gpb + gl);
       for (int c = l; c < nsc; c += tpg) {
-        ts += src[(size_t)c * groups * 2];
-        tq += src[(size_t)c * groups * 2 + 1];
+        const float2 v = src[(size_t)c * groups];
+        ts += v.x;
+        tq += v.y;
       }
     }
     s_a[tid] = ts;
@@ -137,41 +158,36 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(f16* __restrict__ y, int 
     s_rstd[tid] = rsqrtf(var + eps);
   }
   __syncthreads();
-  for (int c = tid; c < nvb * 8; c += 256) {
-    const int g = c / cpg;
-    const int cg = part * nvb * 8 + c;
-    const float a = s_rstd[g] * gamma[cg];
-    s_a[c] = a;
-    s_b[c] = beta[cg] - s_mean[g] * a;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = tid + k * 256;
+    if (c < nvb * 8) {
+      const int g = c / cpg;
+      const float a = s_rstd[g] * gpre[k];
+      s_a[c] = a;
+      s_b[c] = bpre[k] - s_mean[g] * a;
+    }
   }
   __syncthreads();
-  if (prow >= P) return;
-  const int c0 = (part * nvb + cv) * 8;
+  if (!active) return;
   float a[8], bb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { a[j] = s_a[cv * 8 + j]; bb[j] = s_b[cv * 8 + j]; }
-  const int pbeg = chunk * ppc;
-  const int pend = min(HW, pbeg + ppc);
-  const f16* xb = x + ((size_t)b * HW) * ldx + c0;
-  f16* yb = y + ((size_t)b * HW) * ldy + c0;
-  int pix = pbeg + prow;
-  for (; pix + 3 * P < pend; pix += 4 * P) {
-    f16x8 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f16x8*>(xb + (size_t)(pix + u * P) * ldx);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < 4; ++u) {
+    const int pix = pbeg + prow + u * P;
+    if (pix < pend) {
       f16x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float f = (float)v[u][j] * a[j] + bb[j];
+        float f = (float)xv[u][j] * a[j] + bb[j];
         if (with_silu) f = silu_f(f);
         o[j] = (f16)f;
       }
-      *reinterpret_cast<f16x8*>(yb + (size_t)(pix + u * P) * ldy) = o;
+      *reinterpret_cast<f16x8*>(yb + (size_t)pix * ldy) = o;
     }
   }
-  for (; pix < pend; pix += P) {
+  for (int pix = pbeg + prow + 4 * P; pix < pend; pix += P) {
     const f16x8 v = *reinterpret_cast<const f16x8*>(xb + (size_t)pix * ldx);
     f16x8 o;
 #pragma unroll
@@ -197,8 +213,8 @@ int groupnorm_nhwc(f16* y, int ldy, const f16* x, int ldx, const float* gamma, c
   const int chunks = gn_chunks(HW);
   const int ppc = cdiv(HW, chunks);
   dim3 grid(chunks, parts, B);
-  // statistics use coarser chunks (~64 KB of activations each, at most 128): every apply block re-reduces all of them
-  int sc = (int)(((size_t)HW * C * 2) >> 16);
+  // statistics chunks: ~16 KB of activations each, at most 128 (every apply block re-reduces all of them)
+  int sc = (int)(((size_t)HW * C * 2) >> 14);
   sc = sc < 1 ? 1 : (sc > 128 ? 128 : sc);
   if (sc > chunks) sc = chunks;
   const int sppc = cdiv(HW, sc);
