@@ -15,8 +15,13 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+import os
+
 from .. import ops
 from ..runtime import CONTEXT_CACHED, HINT_CACHED
+
+# replay the per-step apply_model from a hipGraph once hint / context are cached (SDEO_GRAPH=0: eager launches)
+USE_GRAPH = os.environ.get("SDEO_GRAPH", "1") != "0"
 
 
 def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=True):
@@ -174,9 +179,12 @@ class DDIMSampler(object):
         flags = 0
         pair = {"c_concat": None, "c_crossattn": None}
         if key == self._cache_key:
-            flags = HINT_CACHED | CONTEXT_CACHED
-            eps2 = m.rt.configure(2 * b, x.shape[2], x.shape[3]).apply_model(
-                torch.cat([x, x]), None, torch.cat([t, t]), None, m.control_scales, m.only_mid_control, flags)
+            rt = m.rt.configure(2 * b, x.shape[2], x.shape[3])
+            if USE_GRAPH:
+                eps2 = rt.apply_model_graphed(torch.cat([x, x]), torch.cat([t, t]), m.control_scales, m.only_mid_control)
+            else:
+                eps2 = rt.apply_model(torch.cat([x, x]), None, torch.cat([t, t]), None, m.control_scales,
+                                      m.only_mid_control, HINT_CACHED | CONTEXT_CACHED)
         else:
             pair = {"c_concat": [torch.cat([hint_c, hint_u])], "c_crossattn": [torch.cat([ctx_c, ctx_u])]}
             eps2 = m.apply_model(torch.cat([x, x]), torch.cat([t, t]), pair)

@@ -121,6 +121,7 @@ class SdeoRuntime:
     # ---------------------------------------------------------------- shapes
     def configure(self, n: int, h: int, w: int):
         if (n, h, w) != (self.n, self.h, self.w):
+            self._graph_key = None
             check(self.lib.sdeo_configure(self.handle, C.c_int(n), C.c_int(h), C.c_int(w)), "configure")
             self.n, self.h, self.w = n, h, w
         return self
@@ -196,6 +197,31 @@ class SdeoRuntime:
         check(self.lib.sdeo_apply_model(self.handle, ptr(x), ptr(hint), ptr(t), ptr(ctx), self._scales(scales),
                                         C.c_int(int(only_mid_control)), C.c_int(flags), ptr(eps), cur_stream()), "apply_model")
         return eps
+
+    def apply_model_graphed(self, x, t, scales=None, only_mid_control=False):
+        """apply_model with the hint block and context K/V cached, replayed from a hipGraph (the reference captures its
+        TensorRT engines the same way, `Engine.py:139-152`).  The graph holds both streams of the step (ControlNet on the
+        side stream, UNet encoder on the main one), so the GPU sees the whole fork/join at once.  Inputs are copied into
+        fixed device buffers; the returned eps tensor is owned by the runtime (valid until the next call)."""
+        key = (self.n, self.h, self.w, tuple(float(s) for s in (scales or [])), bool(only_mid_control))
+        if getattr(self, "_graph_key", None) != key:
+            u = self.ucfg
+            self._gx = torch.zeros((self.n, u.in_channels, self.h, self.w), dtype=torch.float32, device=self.device)
+            self._gt = torch.zeros((self.n,), dtype=torch.int64, device=self.device)
+            self._geps = torch.zeros((self.n, u.out_channels, self.h, self.w), dtype=torch.float32, device=self.device)
+            self._gx.copy_(x)
+            self._gt.copy_(t)
+            flags = HINT_CACHED | CONTEXT_CACHED
+            self.apply_model(self._gx, None, self._gt, None, scales, only_mid_control, flags, self._geps)   # warm-up, eager
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.apply_model(self._gx, None, self._gt, None, scales, only_mid_control, flags, self._geps)
+            self._graph, self._graph_key = g, key
+        self._gx.copy_(x)
+        self._gt.copy_(t)
+        self._graph.replay()
+        return self._geps
 
     def vae_decode(self, z, want_u8: bool = False):
         """z (b,4,h,w) latents (sampler output) -> images (b,3,8h,8w) fp32 in [-1,1] (+ optional NHWC uint8)."""
