@@ -34,7 +34,7 @@ struct AP {
 };
 
 template <int D16>
-__global__ __launch_bounds__(256) void attention_kernel(const AP p) {
+__global__ __launch_bounds__(256, (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))) void attention_kernel(const AP p) {
   constexpr int DT = (D16 + 1) / 2;                          // 32-row tiles of O^T
   constexpr int KROW = D16 * 32 + ((D16 * 2) % 2 == 0 ? 16 : 0);  // K tile row bytes (odd multiple of 16)
   constexpr int VROW = 64 * 2 + 8;                           // V^T tile row bytes (odd multiple of 8)
@@ -71,57 +71,69 @@ __global__ __launch_bounds__(256) void attention_kernel(const AP p) {
   const f16* kbase = p.k + (size_t)b * p.TkS * p.ldk + h * d;
   const f16* vbase = p.vt + (size_t)h * d * p.ldvt + (size_t)b * p.TkSv;
   const int ntiles = (p.Tk + 63) / 64;
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  const f16x8 zero8 = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
 
-  uint4 kr[KPASS], vr[VPASS];
+  // per-thread staging state, hoisted out of the key loop: source pointers (advanced by one tile per call) and LDS
+  // destinations of the 16-byte chunks this thread moves
+  f16x8 kr[KPASS], vr[VPASS];
+  const f16* kptr[KPASS];
+  const f16* vptr[VPASS];
+  int krow[KPASS], kdst[KPASS], vkey[VPASS], vdst[VPASS];
+#pragma unroll
+  for (int i = 0; i < KPASS; ++i) {
+    const int it = tid + i * 256;
+    const int row = it / KCH, c = it - row * KCH;
+    const bool use = it < KITEMS && c * 8 < d;
+    krow[i] = use ? row : (1 << 30);                 // never valid
+    kptr[i] = kbase + (size_t)row * p.ldk + c * 8;
+    kdst[i] = it < KITEMS ? row * KROW + c * 16 : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < VPASS; ++i) {
+    const int it = tid + i * 256;
+    const int row = it >> 3, c = it & 7;
+    const bool use = it < VITEMS && row < d;
+    vkey[i] = use ? c * 8 : (1 << 30);
+    vptr[i] = vbase + (size_t)row * p.ldvt + c * 8;
+    vdst[i] = it < VITEMS ? row * VROW + c * 16 : -1;
+  }
+  const size_t kstep = (size_t)64 * p.ldk;
   auto load_tile = [&](int kt) {
     const int key0 = kt * 64;
 #pragma unroll
     for (int i = 0; i < KPASS; ++i) {
-      const int it = tid + i * 256;
-      const int row = it / KCH, c = it - row * KCH;
-      const int key = key0 + row;
-      kr[i] = (it < KITEMS && key < p.Tk && c * 8 < d)
-                  ? *reinterpret_cast<const uint4*>(kbase + (size_t)key * p.ldk + c * 8) : zero4;
+      kr[i] = (key0 + krow[i] < p.Tk) ? *reinterpret_cast<const f16x8*>(kptr[i]) : zero8;
+      kptr[i] += kstep;
     }
 #pragma unroll
     for (int i = 0; i < VPASS; ++i) {
-      const int it = tid + i * 256;
-      const int row = it >> 3, c = it & 7;
-      const int key = key0 + c * 8;
-      uint4 v = zero4;
-      if (it < VITEMS && row < d && key < p.Tk) {
-        v = *reinterpret_cast<const uint4*>(vbase + (size_t)row * p.ldvt + key);
+      const int key = key0 + vkey[i];
+      f16x8 v = zero8;
+      if (key < p.Tk) {
+        v = *reinterpret_cast<const f16x8*>(vptr[i]);
         if (key + 8 > p.Tk) {  // partially valid chunk: zero the keys >= Tk (P is 0 there, V must be finite)
-          f16x8 t = *reinterpret_cast<f16x8*>(&v);
 #pragma unroll
           for (int j = 0; j < 8; ++j)
-            if (key + j >= p.Tk) t[j] = (f16)0.f;
-          v = *reinterpret_cast<uint4*>(&t);
+            if (key + j >= p.Tk) v[j] = (f16)0.f;
         }
       }
       vr[i] = v;
+      vptr[i] += 64;
     }
   };
   auto store_tile = [&](int stage) {
     char* ks_ = smem + stage * STAGE;
     char* vs_ = ks_ + KBYTES;
 #pragma unroll
-    for (int i = 0; i < KPASS; ++i) {
-      const int it = tid + i * 256;
-      const int row = it / KCH, c = it - row * KCH;
-      if (it < KITEMS) *reinterpret_cast<uint4*>(ks_ + row * KROW + c * 16) = kr[i];
-    }
+    for (int i = 0; i < KPASS; ++i)
+      if (kdst[i] >= 0) *reinterpret_cast<f16x8*>(ks_ + kdst[i]) = kr[i];
 #pragma unroll
-    for (int i = 0; i < VPASS; ++i) {
-      const int it = tid + i * 256;
-      const int row = it >> 3, c = it & 7;
-      if (it < VITEMS) {
-        uint2* dst = reinterpret_cast<uint2*>(vs_ + row * VROW + c * 16);   // rows are only 8-byte aligned
-        dst[0] = make_uint2(vr[i].x, vr[i].y);
-        dst[1] = make_uint2(vr[i].z, vr[i].w);
+    for (int i = 0; i < VPASS; ++i)
+      if (vdst[i] >= 0) {
+        f16x4* dst = reinterpret_cast<f16x4*>(vs_ + vdst[i]);   // rows are only 8-byte aligned
+        dst[0] = __builtin_shufflevector(vr[i], vr[i], 0, 1, 2, 3);
+        dst[1] = __builtin_shufflevector(vr[i], vr[i], 4, 5, 6, 7);
       }
-    }
   };
 
   f32x16 o[DT];
@@ -155,39 +167,41 @@ __global__ __launch_bounds__(256) void attention_kernel(const AP p) {
       }
     }
     // ---- online softmax (base-2), key index of s[kb][r] = kt*64 + kb*32 + (r&3) + 8*(r>>2) + 4*lh
+    //      the running max is kept in scaled units (score * scale * log2 e); the scale itself is folded into one fma
     const bool tail = (kt + 1) * 64 > p.Tk;
     float mx = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float v = s[kb][r] * p.scale_log2;
         if (tail) {
           const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (key >= p.Tk) v = -INFINITY;
+          if (key >= p.Tk) s[kb][r] = -INFINITY;
         }
-        s[kb][r] = v;
-        mx = fmaxf(mx, v);
+        mx = fmaxf(mx, s[kb][r]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    const float m_new = fmaxf(m_run, mx * p.scale_log2);
     float rs = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2, -m_new));
         s[kb][r] = pv;
         rs += pv;
       }
     rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
+    if (__any(m_new > m_run)) {      // wave-uniform: after the first few tiles the running max rarely moves
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+      for (int t = 0; t < DT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      m_run = m_new;
+    }
+    l_run += rs;
 
     // ---- O^T += V^T P^T : P^T fragments straight from the score registers
 #pragma unroll
@@ -201,10 +215,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AP p) {
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
           const char* vrow = vs_ + (t * 32 + lq) * VROW + kofs;
-          const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
-          const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
-          uint4 vv = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          const f16x8 vf = *reinterpret_cast<f16x8*>(&vv);
+          const f16x4 lo = *reinterpret_cast<const f16x4*>(vrow);
+          const f16x4 hi = *reinterpret_cast<const f16x4*>(vrow + 16);
+          const f16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
         }
       }

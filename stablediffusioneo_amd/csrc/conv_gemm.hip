@@ -63,7 +63,7 @@ __device__ __forceinline__ int swz_chunk(int row, int chunk) {
 // ---- epilogue shared by both kernels: lane holds n = nb + fq*4 + {0..3} (4 consecutive channels) of pixel m
 template <int NI, int MI, int TM, int TN>
 __device__ __forceinline__ void epilogue(const KP& p, f32x4 (&acc)[NI][MI], int m0, int n0, int wm, int wn, int frow, int fq, int z,
-                                         const f32x4* bpre = nullptr) {
+                                         const f32x4 (&bpre)[NI], bool use_bpre) {
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
     const int m = m0 + wm * TM + j * 16 + frow;
@@ -80,7 +80,7 @@ __device__ __forceinline__ void epilogue(const KP& p, f32x4 (&acc)[NI][MI], int 
       }
       if (p.bias) {
         if (p.bias_per_row) v += p.bias[m];
-        else if (bpre) v += bpre[i];
+        else if (use_bpre) v += bpre[i];
         else v += *reinterpret_cast<const f32x4*>(p.bias + n);
       }
       if (p.bias2) v += *reinterpret_cast<const f32x4*>(p.bias2 + (size_t)b * p.ld_bias2 + n);
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KP p) {
       }
     }
   }
-  epilogue<NI, MI, TM, TN>(p, acc, m0, n0, wm, wn, frow, fq, z, use_bpre ? bpre : nullptr);
+  epilogue<NI, MI, TM, TN>(p, acc, m0, n0, wm, wn, frow, fq, z, bpre, use_bpre);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -439,7 +439,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KP p) {
       __syncthreads();
     }
   }
-  epilogue<NI, MI, TM, TN>(p, acc, m0, n0, wm, wn, frow, fq, z);
+  f32x4 nob[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) nob[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  epilogue<NI, MI, TM, TN>(p, acc, m0, n0, wm, wn, frow, fq, z, nob, false);
 }
 
 // split-K: sum the fp32 partial slabs and apply the epilogue. One thread per 4 output channels.
