@@ -8,13 +8,16 @@
 // fixed-order sum) instead of atomicAdd into a memset workspace, so results are bitwise reproducible.
 // Numerics follow PyTorch's F.group_norm (`util.py:217-219`, `attention.py:88-89`): fp32 mean / biased
 // variance over (C/G)*H*W elements, y = (x-mean)*rsqrt(var+eps)*gamma+beta.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace sdeo {
 
 // statistics chunks per image: enough blocks to fill 256 CUs at the 64x64 level, capped so the
 // second-level sum stays short
-int gn_chunks(int HW) { const int c = cdiv(HW, 16); return c > 256 ? 256 : c; }
+// upper bound of the statistics chunks per image (sizes the partial-sum workspace)
+int gn_chunks(int HW) { const int c = cdiv(HW, 8); return c > 128 ? 128 : (c < 1 ? 1 : c); }
 
 // Channel vectors (8 x fp16 = 16 B) handled by one block: the largest divisor of C/8 that is <= 256 and
 // covers whole groups.  Returns 0 when no such split exists.
@@ -51,6 +54,19 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
     const f16* base = x + ((size_t)b * HW) * ldx + c0;
     // 4 independent 16-byte loads in flight per thread (the loop is latency-bound otherwise)
     int pix = pbeg + prow;
+    for (; pix + 7 * P < pend; pix += 8 * P) {
+      f16x8 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f16x8*>(base + (size_t)(pix + u * P) * ldx);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = (float)v[u][j];
+          s[j] += f;
+          q[j] += f * f;
+        }
+    }
     for (; pix + 3 * P < pend; pix += 4 * P) {
       f16x8 v[4];
 #pragma unroll
@@ -77,18 +93,27 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s_sum[tid * 8 + j] = s[j]; s_sq[tid * 8 + j] = q[j]; }
   __syncthreads();
-  // one thread per group of this block: fixed-order sum over pixel rows and the group's channels
+  // tpg threads per group: each sums a fixed slice of the (pixel row, channel) entries, then a fixed-order butterfly
   const int gpb = nvb * 8 / cpg;    // groups per block
-  if (tid < gpb) {
-    float ts = 0.f, tq = 0.f;
-    const int cbeg = tid * cpg;     // channel offset inside the block's channel slab
-    for (int pr = 0; pr < P; ++pr)
-      for (int c = cbeg; c < cbeg + cpg; ++c) {
-        const int idx = (pr * nvb + (c >> 3)) * 8 + (c & 7);
-        ts += s_sum[idx];
-        tq += s_sq[idx];
-      }
-    const int g = part * gpb + tid;
+  int tpg = 256 / gpb;
+  tpg = tpg >= 32 ? 32 : (tpg >= 16 ? 16 : (tpg >= 8 ? 8 : (tpg >= 4 ? 4 : (tpg >= 2 ? 2 : 1))));   // power of two <= 32
+  const int gl = tid / tpg, l = tid - gl * tpg;
+  float ts = 0.f, tq = 0.f;
+  if (gl < gpb) {
+    const int n = P * cpg;            // entries of this group: (pr, c) with c in [gl*cpg, gl*cpg + cpg)
+    for (int e = l; e < n; e += tpg) {
+      const int pr = e / cpg, c = gl * cpg + (e - pr * cpg);
+      const int idx = (pr * nvb + (c >> 3)) * 8 + (c & 7);
+      ts += s_sum[idx];
+      tq += s_sq[idx];
+    }
+  }
+  for (int off = tpg >> 1; off >= 1; off >>= 1) {
+    ts += __shfl_xor(ts, off, 64);
+    tq += __shfl_xor(tq, off, 64);
+  }
+  if (gl < gpb && l == 0) {
+    const int g = part * gpb + gl;
     float* dst = partials + (((size_t)b * nchunks + chunk) * groups + g) * 2;
     dst[0] = ts;
     dst[1] = tq;
@@ -136,10 +161,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(f16* __restrict__ y, int 
     float ts = 0.f, tq = 0.f;
     if (gl < gpb) {
       const float2* src = reinterpret_cast<const float2*>(partials) + ((size_t)b * nsc * groups + part * gpb + gl);
-      for (int c = l; c < nsc; c += tpg) {
-        const float2 v = src[(size_t)c * groups];
-        ts += v.x;
-        tq += v.y;
+      for (int c0 = l; c0 < nsc; c0 += 8 * tpg) {       // 8 independent loads in flight, summed in a fixed order
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int c = c0 + u * tpg;
+          v[u] = c < nsc ? src[(size_t)c * groups] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { ts += v[u].x; tq += v[u].y; }
       }
     }
     s_a[tid] = ts;
@@ -210,13 +240,16 @@ int groupnorm_nhwc(f16* y, int ldy, const f16* x, int ldx, const float* gamma, c
   SDEO_CHECK(nvb > 0, "groupnorm: unsupported channel split C=%d groups=%d", C, groups);
   const int cpg = C / groups;
   const int parts = (C / 8) / nvb;
-  const int chunks = gn_chunks(HW);
+  // Both kernels are chains of dependent memory round trips (~0.5 us each on this chip), so the chunking is chosen to
+  // give every thread ONE batch of independent loads: 4 pixels per thread in apply (prefetched before the statistics
+  // are known), 8 in the statistics pass; P = pixel rows a block covers per sweep.
+  const int P = 256 / nvb;
+  int chunks = cdiv(HW, 4 * P);
+  if (chunks > 2048) chunks = 2048;
   const int ppc = cdiv(HW, chunks);
   dim3 grid(chunks, parts, B);
-  // statistics chunks: ~16 KB of activations each, at most 128 (every apply block re-reduces all of them)
-  int sc = (int)(((size_t)HW * C * 2) >> 14);
-  sc = sc < 1 ? 1 : (sc > 128 ? 128 : sc);
-  if (sc > chunks) sc = chunks;
+  int sc = cdiv(HW, 8 * P);
+  { const int mxs = gn_chunks(HW) < 128 ? gn_chunks(HW) : 128; sc = sc < 1 ? 1 : (sc > mxs ? mxs : sc); }
   const int sppc = cdiv(HW, sc);
   dim3 sgrid(sc, parts, B);
   hipLaunchKernelGGL(gn_stats_kernel, sgrid, dim3(256), 0, stream, x, ldx, HW, C, cpg, nvb, partials, sc, groups, sppc);
