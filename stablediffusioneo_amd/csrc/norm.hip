@@ -278,12 +278,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(f16* __restrict__ y, int
   if (row >= rows) return;
   const int nvec = C / 8;
   f16x8 v[VPL];
+  f32x4 gv[VPL][2], bv[VPL][2];      // gamma / beta fetched up front: independent of the row statistics
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int vi = lane + i * 64;
     if (vi < nvec) {
       v[i] = *reinterpret_cast<const f16x8*>(x + (size_t)row * ldx + vi * 8);
+      gv[i][0] = *reinterpret_cast<const f32x4*>(gamma + vi * 8); gv[i][1] = *reinterpret_cast<const f32x4*>(gamma + vi * 8 + 4);
+      bv[i][0] = *reinterpret_cast<const f32x4*>(beta + vi * 8); bv[i][1] = *reinterpret_cast<const f32x4*>(beta + vi * 8 + 4);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int vi = lane + i * 64;
+    if (vi < nvec) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += (float)v[i][j];
     }
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(f16* __restrict__ y, int
       f16x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        o[j] = (f16)(((float)v[i][j] - mean) * rstd * gamma[vi * 8 + j] + beta[vi * 8 + j]);
+        o[j] = (f16)(((float)v[i][j] - mean) * rstd * gv[i][j >> 2][j & 3] + bv[i][j >> 2][j & 3]);
       *reinterpret_cast<f16x8*>(y + (size_t)row * ldy + vi * 8) = o;
     }
   }
