@@ -44,6 +44,11 @@ const char* sdeo_last_error(void);
 int sdeo_version(void);
 /* tuning hook for tools/tune_gemm.py: force tile config / split-K of the following conv/GEMM launches (-1, 0 = heuristic) */
 void sdeo_debug_force_gemm_plan(int tile, int splitk);
+/* GEMM plan table: (tile, split-K) per problem shape key {M,N,K,Cin,R,stride,ups,Hi,Wi,B}.  sdeo_configure measures
+ * unknown shapes on the device (SDEO_AUTOTUNE=0 disables); known ones come from the table, which
+ * stablediffusioneo_amd/tuned_plans_gfx950.json pre-loads so that runs are reproducible and start fast. */
+void sdeo_set_tuned_gemm_plan(const int* key10, int tile, int splitk);
+const char* sdeo_tuned_gemm_plans_json(void);
 /* y = silu(x) on n fp16 elements: launch-floor probe for tools/launch_floor.py */
 int sdeo_debug_silu(void* y, const void* x, int64_t n, void* stream);
 

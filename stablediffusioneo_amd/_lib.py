@@ -58,8 +58,30 @@ def load(path: str = LIB_PATH):
                  "sdeo_device_bytes"):
         getattr(lib, name).restype = C.c_size_t
     lib.sdeo_device_bytes.argtypes = [C.c_void_p]
+    lib.sdeo_tuned_gemm_plans_json.restype = C.c_char_p
     _lib = lib
+    load_tuned_plans(lib)
     return lib
+
+
+TUNED_PLANS = os.path.join(HERE, "tuned_plans_gfx950.json")
+
+
+def load_tuned_plans(lib, path: str = TUNED_PLANS) -> int:
+    """Push the committed (tile, split-K) table into the library; returns the number of entries."""
+    import json
+    if not os.path.exists(path):
+        return 0
+    rows = json.load(open(path))
+    for r in rows:
+        lib.sdeo_set_tuned_gemm_plan((C.c_int * 10)(*r[:10]), C.c_int(r[10]), C.c_int(r[11]))
+    return len(rows)
+
+
+def dump_tuned_plans(lib=None):
+    import json
+    lib = lib or load()
+    return json.loads(lib.sdeo_tuned_gemm_plans_json().decode())
 
 
 def check(rc: int, what: str = "sdeo"):

@@ -31,6 +31,12 @@ extern "C" {
 const char* sdeo_last_error(void) { return g_last_error.c_str(); }
 int sdeo_version(void) { return 100; }
 void sdeo_debug_force_gemm_plan(int tile, int splitk) { conv_gemm_debug_force(tile, splitk); }
+void sdeo_set_tuned_gemm_plan(const int* key10, int tile, int splitk) { conv_gemm_set_tuned(key10, tile, splitk); }
+const char* sdeo_tuned_gemm_plans_json(void) {
+  static std::string s;
+  s = conv_gemm_tuned_json();
+  return s.c_str();
+}
 int sdeo_debug_silu(void* y, const void* x, int64_t n, void* stream) { return silu((f16*)y, (const f16*)x, n, S(stream)); }
 
 size_t sdeo_groupnorm_workspace_bytes(int n, int hw, int groups) {

@@ -656,6 +656,28 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
   return 0;
 }
 
+// tuned-plan table I/O (stablediffusioneo_amd/tuned_plans_gfx950.json is produced by tools/tune_plans.py on an MI355X and
+// loaded at start-up, so production runs neither re-measure nor vary their plans from run to run)
+void conv_gemm_set_tuned(const int key[10], int tile, int splitk) {
+  ShapeKey k;
+  for (int i = 0; i < 10; ++i) k[i] = key[i];
+  if (tile >= 0 && tile < kNumTiles && kTiles[tile].kind == TK_DMA && splitk >= 1) g_tuned[k] = {tile, splitk};
+}
+
+std::string conv_gemm_tuned_json() {
+  std::string out = "[";
+  char buf[256];
+  bool first = true;
+  for (auto& kv : g_tuned) {
+    snprintf(buf, sizeof(buf), "%s[%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d]", first ? "" : ",", kv.first[0], kv.first[1], kv.first[2],
+             kv.first[3], kv.first[4], kv.first[5], kv.first[6], kv.first[7], kv.first[8], kv.first[9], kv.second.first,
+             kv.second.second);
+    out += buf;
+    first = false;
+  }
+  return out + "]";
+}
+
 // ------------------------------------------------------------------------------------------------
 // autotune: measure every (tile, split-K) candidate for one problem on the device and remember the fastest.
 // Called once per distinct shape from sdeo_configure (never on the hot path, never under graph capture).

@@ -40,7 +40,9 @@ const char* conv_gemm_kernel_name(const ConvGemm& p);
 void conv_gemm_debug_force(int tile, int splitk);
 // one-time on-device plan search for p's shape (p needs valid scratch pointers); workspace to reserve for it
 int conv_gemm_autotune(const ConvGemm& p, hipStream_t stream);
-size_t conv_gemm_autotune_workspace_bytes(const ConvGemm& p);   // tuning hook: -1 / 0 restore the heuristic
+size_t conv_gemm_autotune_workspace_bytes(const ConvGemm& p);
+void conv_gemm_set_tuned(const int key[10], int tile, int splitk);
+std::string conv_gemm_tuned_json();   // [[M,N,K,Cin,R,stride,ups,Hi,Wi,B,tile,splitk],...]   // tuning hook: -1 / 0 restore the heuristic
 
 // ------------------------------------------------------------------------------------------
 // GroupNorm (NHWC fp16, fp32 statistics, eps honoured) + optional SiLU; two launches:
