@@ -164,8 +164,15 @@ def main():
         dom = max(mm, key=lambda k: k["total_ms"])
         tot_ms = sum(k["total_ms"] for k in prof)
         ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+        traffic, tnote = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):          # PMC numbers cannot be taken inside this process: committed rocprofv3 --pmc result
+            tj = json.load(open(tpath)).get(dom["kernel"])
+            if tj:
+                traffic, tnote = tj["traffic_bytes"], tj["shape"]
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_TFLOPS_F16, 4), "traffic": None, "kernel": dom["kernel"],
+                "frac": round(ach / PEAK_TFLOPS_F16, 4), "traffic": traffic, "traffic_measured_on": tnote,
+                "kernel": dom["kernel"],
                 "launches_per_image": dom["launches"], "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2),
                 "share_of_device_time": round(dom["total_ms"] / tot_ms, 3),
                 "by_kernel_ms_per_image": {k["kernel"]: round(k["total_ms"], 2) for k in

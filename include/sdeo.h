@@ -44,6 +44,7 @@ const char* sdeo_last_error(void);
 int sdeo_version(void);
 /* tuning hook for tools/tune_gemm.py: force tile config / split-K of the following conv/GEMM launches (-1, 0 = heuristic) */
 void sdeo_debug_force_gemm_plan(int tile, int splitk);
+void sdeo_debug_force_gemm_order(int order); /* -1 heuristic, 0 M-fastest, 1 N-fastest tile order within an XCD */
 /* GEMM plan table: (tile, split-K) per problem shape key {M,N,K,Cin,R,stride,ups,Hi,Wi,B}.  sdeo_configure measures
  * unknown shapes on the device (SDEO_AUTOTUNE=0 disables); known ones come from the table, which
  * stablediffusioneo_amd/tuned_plans_gfx950.json pre-loads so that runs are reproducible and start fast. */

@@ -48,6 +48,7 @@ struct KP {
   float scale;
   int nk, nk_per_split, splitk;
   int tiles_m, tiles_n;
+  int n_fastest;     // tile order inside an XCD's contiguous run: 1 = all N tiles of an M tile are neighbours
 };
 
 // 256 bytes of zeros: DMA source for padded / out-of-range rows
@@ -135,7 +136,8 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+  const int tm = p.n_fastest ? tile / p.tiles_n : tile % p.tiles_m;
+  const int tn = p.n_fastest ? tile % p.tiles_n : tile / p.tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.z;
   const int kbeg = z * p.nk_per_split;
@@ -512,7 +514,8 @@ struct Plan { int tile; int splitk; int nk; int tiles_m, tiles_n; };
 static bool is_fast(const ConvGemm& p) { return p.Cin % 64 == 0; }
 
 // tuning hook (tools/tune_gemm.py): force the tile configuration / split-K factor of every following launch
-static int g_force_tile = -1, g_force_splitk = 0;
+static int g_force_tile = -1, g_force_splitk = 0, g_force_order = -1;
+void conv_gemm_debug_force_order(int order) { g_force_order = order; }
 void conv_gemm_debug_force(int tile, int splitk) { g_force_tile = tile; g_force_splitk = splitk; }
 
 // plans measured on this device by conv_gemm_autotune (shape -> tile, split-K); consulted before the heuristic
@@ -618,6 +621,15 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
   kp.act = p.act; kp.bias_per_row = p.bias_per_row; kp.scale = p.scale;
   kp.nk = pl.nk; kp.splitk = pl.splitk; kp.nk_per_split = cdiv(pl.nk, pl.splitk);
   kp.tiles_m = pl.tiles_m; kp.tiles_n = pl.tiles_n;
+  {
+    // Each of the 8 XCDs has a private L2 and gets a contiguous run of tiles.  With N fastest every activation row is
+    // fetched by one XCD but every XCD streams all the weights; with M fastest it is the other way round (each XCD
+    // sees about tiles_n/8 weight panels and every activation row min(8, tiles_n) times).  Pick the cheaper fetch.
+    const double xb = (double)p.M * p.Cin * 2.0 * (p.R * p.S > 1 ? 1.3 : 1.0), wb = (double)p.N * p.K * 2.0;
+    const double cost_n_fast = xb + 8.0 * wb;
+    const double cost_m_fast = (pl.tiles_n < 8 ? pl.tiles_n : 8) * xb + wb * (pl.tiles_n < 8 ? 1.6 : 1.0);
+    kp.n_fastest = g_force_order >= 0 ? g_force_order : (cost_n_fast < cost_m_fast ? 1 : 0);
+  }
   if (pl.splitk > 1) {
     const size_t need = (size_t)pl.splitk * p.M * p.N * sizeof(float);
     SDEO_CHECK(p.workspace && p.workspace_bytes >= need, "conv_gemm: split-K workspace too small (%zu < %zu)",
