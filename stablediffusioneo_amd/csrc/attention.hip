@@ -49,9 +49,17 @@ __global__ __launch_bounds__(256, (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))) void atte
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
-  const int bh = blockIdx.y;
+  // XCD-aware placement (speed only): workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous
+  // run of (batch, head) pairs so the K / V^T of a head stay in ONE private L2 instead of being streamed by all eight
+  const int qtiles = (p.Tq + 127) >> 7;
+  int wg = blockIdx.x, nwg = gridDim.x;
+  {
+    const int q_ = nwg >> 3, r_ = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_) + idx;
+  }
+  const int bh = wg / qtiles;
   const int b = bh / p.H, h = bh - b * p.H;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = (wg - bh * qtiles) * 128 + wave * 32;
   const int qrow = q0 + lq;
   const bool qvalid = qrow < p.Tq;
   const int d = p.d;
@@ -255,7 +263,7 @@ static int launch_attn(const AP& ap, int B, hipStream_t stream) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_done = true;
   }
-  dim3 grid(cdiv(ap.Tq, 128), B * ap.H);
+  dim3 grid(cdiv(ap.Tq, 128) * B * ap.H);
   hipLaunchKernelGGL((attention_kernel<D16>), grid, dim3(256), smem, stream, ap);
   SDEO_HIP(hipGetLastError());
   return 0;
