@@ -33,8 +33,15 @@ struct AP {
   float scale_log2;
 };
 
-template <int D16>
-__global__ __launch_bounds__(256, (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))) void attention_kernel(const AP p) {
+// KS = 1: four waves, each owning 32 queries and walking all keys.  KS = 2 ("key split"): eight waves, the two waves of a
+// pair own the same 32 queries and each takes one 32-key half of every staged tile, so the serial per-tile chain
+// (QK^T -> max -> exp -> PV) per wave halves and twice as many waves hide it; the two partial (m, l, O) states are merged
+// through LDS at the end.  Reduction order is fixed (half 0 then half 1), so results stay deterministic.
+template <int D16, int KS>
+__global__ __launch_bounds__(256 * KS, (KS == 2 ? (D16 <= 4 ? 4 : 2) : (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))))
+void attention_kernel(const AP p) {
+  constexpr int NT = 256 * KS;                               // threads per workgroup
+  constexpr int NKB = 2 / KS;                                // 32-key blocks of a tile each wave handles
   constexpr int DT = (D16 + 1) / 2;                          // 32-row tiles of O^T
   constexpr int KROW = D16 * 32 + ((D16 * 2) % 2 == 0 ? 16 : 0);  // K tile row bytes (odd multiple of 16)
   constexpr int VROW = 64 * 2 + 8;                           // V^T tile row bytes (odd multiple of 8)
@@ -42,13 +49,15 @@ __global__ __launch_bounds__(256, (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))) void atte
   constexpr int VBYTES = DT * 32 * VROW;
   constexpr int STAGE = KBYTES + VBYTES;
   constexpr int KCH = D16 * 2;                               // 16-byte chunk slots per K row
-  constexpr int KITEMS = 64 * KCH, KPASS = (KITEMS + 255) / 256;
-  constexpr int VITEMS = DT * 32 * 8, VPASS = (VITEMS + 255) / 256;
+  constexpr int KITEMS = 64 * KCH, KPASS = (KITEMS + NT - 1) / NT;
+  constexpr int VITEMS = DT * 32 * 8, VPASS = (VITEMS + NT - 1) / NT;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
+  const int qb = KS == 2 ? (wave >> 1) : wave;               // 32-query block of this wave
+  const int kh = KS == 2 ? (wave & 1) : 0;                   // key half of this wave (KS == 2)
   // XCD-aware placement (speed only): workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous
   // run of (batch, head) pairs so the K / V^T of a head stay in ONE private L2 instead of being streamed by all eight
   const int qtiles = (p.Tq + 127) >> 7;
@@ -59,7 +68,7 @@ __global__ __launch_bounds__(256, (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))) void atte
   }
   const int bh = wg / qtiles;
   const int b = bh / p.H, h = bh - b * p.H;
-  const int q0 = (wg - bh * qtiles) * 128 + wave * 32;
+  const int q0 = (wg - bh * qtiles) * 128 + qb * 32;
   const int qrow = q0 + lq;
   const bool qvalid = qrow < p.Tq;
   const int d = p.d;
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(256, (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))) void atte
   int krow[KPASS], kdst[KPASS], vkey[VPASS], vdst[VPASS];
 #pragma unroll
   for (int i = 0; i < KPASS; ++i) {
-    const int it = tid + i * 256;
+    const int it = tid + i * NT;
     const int row = it / KCH, c = it - row * KCH;
     const bool use = it < KITEMS && c * 8 < d;
     krow[i] = use ? row : (1 << 30);                 // never valid
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(256, (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))) void atte
   }
 #pragma unroll
   for (int i = 0; i < VPASS; ++i) {
-    const int it = tid + i * 256;
+    const int it = tid + i * NT;
     const int row = it >> 3, c = it & 7;
     const bool use = it < VITEMS && row < d;
     vkey[i] = use ? c * 8 : (1 << 30);
@@ -163,15 +172,16 @@ __global__ __launch_bounds__(256, (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))) void atte
     const char* vs_ = ks_ + KBYTES;
 
     // ---- S^T = K Q^T for the two 32-key blocks of this tile
-    f32x16 s[2];
+    f32x16 s[NKB];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int ki = 0; ki < NKB; ++ki) {
+      const int kb = KS == 2 ? kh : ki;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+      for (int r = 0; r < 16; ++r) s[ki][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < D16; ++ks) {
         const f16x8 kf = *reinterpret_cast<const f16x8*>(ks_ + (kb * 32 + lq) * KROW + (ks * 2 + lh) * 16);
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
+        s[ki] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[ki], 0, 0, 0);
       }
     }
     // ---- online softmax (base-2), key index of s[kb][r] = kt*64 + kb*32 + (r&3) + 8*(r>>2) + 4*lh
@@ -179,24 +189,27 @@ __global__ __launch_bounds__(256, (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))) void atte
     const bool tail = (kt + 1) * 64 > p.Tk;
     float mx = -INFINITY;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int ki = 0; ki < NKB; ++ki)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         if (tail) {
+          const int kb = KS == 2 ? kh : ki;
           const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (key >= p.Tk) s[kb][r] = -INFINITY;
+          if (key >= p.Tk) s[ki][r] = -INFINITY;
         }
-        mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, s[ki][r]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx * p.scale_log2);
+    // a key half that has not seen a single valid key yet (KS == 2, Tk <= 32) keeps m = -inf: exponentiate against 0
+    const float m_use = (KS == 2 && m_new == -INFINITY) ? 0.f : m_new;
     float rs = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int ki = 0; ki < NKB; ++ki)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2, -m_new));
-        s[kb][r] = pv;
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[ki][r], p.scale_log2, -m_use));
+        s[ki][r] = pv;
         rs += pv;
       }
     rs += __shfl_xor(rs, 32, 64);
@@ -213,12 +226,13 @@ __global__ __launch_bounds__(256, (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))) void atte
 
     // ---- O^T += V^T P^T : P^T fragments straight from the score registers
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int ki = 0; ki < NKB; ++ki)
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
+        const int kb = KS == 2 ? kh : ki;
         f16x8 pf;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (f16)s[kb][8 * st + j];
+        for (int j = 0; j < 8; ++j) pf[j] = (f16)s[ki][8 * st + j];
         const int kofs = (kb * 32 + 16 * st + 4 * lh) * 2;
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
@@ -231,6 +245,33 @@ __global__ __launch_bounds__(256, (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))) void atte
       }
     if (more) store_tile(cur ^ 1);
     __syncthreads();
+  }
+
+  if constexpr (KS == 2) {
+    // ---- merge the two key halves of each query block through LDS (field-major, lane-contiguous: conflict-free).
+    //      The loop's last __syncthreads() already separates the final tile reads from these writes.
+    // A tile of a half that lies entirely past Tk leaves m = -inf, l = 0 there; exp2(-inf - m) = 0 handles it, and half 0
+    // always sees key 0, so m below is finite.
+    constexpr int NF = 2 + DT * 16;
+    float* mg = reinterpret_cast<float*>(smem) + qb * NF * 64 + lane;
+    if (kh == 1) {
+      mg[0] = m_run;
+      mg[64] = l_run;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mg[(2 + t * 16 + r) * 64] = o[t][r];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    const float m1 = mg[0], l1 = mg[64];
+    const float m = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+    l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][r] = o[t][r] * a0 + mg[(2 + t * 16 + r) * 64] * a1;
   }
 
   // ---- normalise and store: o[t][4g..4g+3] = O[qrow][t*32 + 8g + 4lh + 0..3]
@@ -252,21 +293,39 @@ __global__ __launch_bounds__(256, (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))) void atte
   }
 }
 
-template <int D16>
-static int launch_attn(const AP& ap, int B, hipStream_t stream) {
+template <int D16, int KS>
+static int launch_attn_ks(const AP& ap, int B, hipStream_t stream) {
   constexpr int DT = (D16 + 1) / 2;
   constexpr int KROW = D16 * 32 + ((D16 * 2) % 2 == 0 ? 16 : 0);
-  constexpr int smem = 2 * (64 * KROW + DT * 32 * (64 * 2 + 8));
+  constexpr int stage2 = 2 * (64 * KROW + DT * 32 * (64 * 2 + 8));
+  constexpr int merge = KS == 2 ? 4 * (2 + DT * 16) * 64 * 4 : 0;     // LDS of the key-half merge
+  constexpr int smem = stage2 > merge ? stage2 : merge;
   static bool attr_done = false;
   if (!attr_done) {
-    SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<D16>),
+    SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<D16, KS>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_done = true;
   }
   dim3 grid(cdiv(ap.Tq, 128) * B * ap.H);
-  hipLaunchKernelGGL((attention_kernel<D16>), grid, dim3(256), smem, stream, ap);
+  hipLaunchKernelGGL((attention_kernel<D16, KS>), grid, dim3(256 * KS), smem, stream, ap);
   SDEO_HIP(hipGetLastError());
   return 0;
+}
+
+// key split pays when there are enough keys for the serial chain to dominate and the head dim keeps the merge small
+static int attn_key_split(const AP& ap, int d16) {
+  static const int forced = [] { const char* e = getenv("SDEO_ATTN_KS"); return e ? atoi(e) : 0; }();
+  if (d16 > 5) return 1;
+  if (forced) return forced;
+  return ap.Tk >= 128 ? 2 : 1;
+}
+
+template <int D16>
+static int launch_attn(const AP& ap, int B, hipStream_t stream) {
+  if constexpr (D16 <= 5) {
+    if (attn_key_split(ap, D16) == 2) return launch_attn_ks<D16, 2>(ap, B, stream);
+  }
+  return launch_attn_ks<D16, 1>(ap, B, stream);
 }
 
 int attention(f16* o, int ldo, const f16* q, int ldq, const f16* k, int ldk, const f16* vt, int ldvt, int B, int H,

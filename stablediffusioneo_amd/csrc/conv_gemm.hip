@@ -27,6 +27,8 @@
 #include <array>
 #include <map>
 
+#include <utility>
+
 #include "kernels.h"
 
 namespace sdeo {
@@ -48,6 +50,7 @@ struct KP {
   float scale;
   int nk, nk_per_split, splitk;
   int tiles_m, tiles_n;
+  int dbg;           // SDEO_DBG_GEMM (measurement only): bit 0 = activation DMAs read the zero page, bit 1 = weight DMAs do
   int n_fastest;     // tile order inside an XCD's contiguous run: 1 = all N tiles of an M tile are neighbours
 };
 
@@ -114,6 +117,20 @@ __device__ __forceinline__ int xcd_remap(int wg, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// compile-time loop (the LDS offsets of the inline-asm fragment reads must be immediates)
+template <int N, typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read128(f16x8& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -122,18 +139,27 @@ __device__ __forceinline__ void wait_vmcnt() {
 // ------------------------------------------------------------------------------------------------
 // main kernel: LDS-DMA ring, Cin % 64 == 0
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int STAGES, bool UPS>
-__global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KP p) {
-  constexpr int BK = 64, CPR = 8, RPP = 32;
-  constexpr int XP = BM / RPP, WP = BN / RPP, L = XP + WP;     // DMA instructions per thread per stage
+// WS ("wave-specialised"): 8 waves, waves 0-3 only read fragments and issue MFMAs, waves 4-7 only issue the LDS-DMAs.
+// An LDS-DMA instruction stalls its wave for ~60-180 clocks at issue (measured); with one
+// workgroup per CU that stall sat in front of every K-step's MFMAs.  Same ring protocol, one barrier per K-step for
+// both roles: the loaders retire step `it` (counted vmcnt) BEFORE barrier `it`, the MFMA waves read it AFTER; the
+// loaders refill slot (it-1) % STAGES after barrier `it`, which every MFMA wave only reaches once its reads of step
+// it-1 have fed its MFMAs.
+template <int BM, int BN, int STAGES, bool UPS, bool WS>
+__global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP p) {
+  constexpr int BK = 64, RPP = 32;
+  constexpr int XP = BM / RPP, WP = BN / RPP, L = XP + WP;     // DMA instructions per loading thread per stage
   constexpr int TM = BM / 2, TN = BN / 2, MI = TM / 16, NI = TN / 16;
   constexpr int XBYTES = BM * BK * 2, WBYTES = BN * BK * 2, STAGE = XBYTES + WBYTES;
   constexpr int PF = STAGES - 1;                                // K-steps of loads issued ahead of the compute
-  static_assert(PF >= 1 && PF <= 3, "ring depth");
+  static_assert(PF >= 1 && PF <= 4, "ring depth");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool do_load = !WS || wave_all >= 4;                   // wave-uniform roles
+  const bool do_mma = !WS || wave_all < 4;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // indices inside the role
   const int wm = wave & 1, wn = wave >> 1;
   const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
   const int tm = p.n_fastest ? tile / p.tiles_n : tile % p.tiles_m;
@@ -156,50 +182,52 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KP p) {
   const char* xrow[XP];
   unsigned vmask[XP];
   int pixbase[UPS ? XP : 1], hb[UPS ? XP : 1], wb[UPS ? XP : 1];
-  const int Hv = UPS ? 2 * p.Hi : p.Hi, Wv = UPS ? 2 * p.Wi : p.Wi;
-  const int R = p.K / (p.S * p.Cin);
-  const bool linear = !UPS && p.K == p.Cin && p.stride == 1 && p.pad == 0;   // Linear / conv1x1: row m IS pixel m
-#pragma unroll
-  for (int i = 0; i < XP; ++i) {
-    const int m = m0 + lrow + i * RPP;
-    const bool mv = m < p.M;
-    if (linear) {
-      vmask[i] = mv ? 1u : 0u;
-      xrow[i] = reinterpret_cast<const char*>(p.x) + ((long)m * p.ldx + cl * 8) * 2;
-      continue;
-    }
-    const int mm = mv ? m : 0;
-    const int b = mm / p.HoWo;
-    const int rem = mm - b * p.HoWo;
-    const int ho = rem / p.Wo;
-    const int wo = rem - ho * p.Wo;
-    const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
-    // taps inside the image: rows rlo..rhi-1, columns slo..shi-1
-    const int rlo = max(0, -h0), rhi = min(R, Hv - h0), slo = max(0, -w0), shi = min(p.S, Wv - w0);
-    const unsigned sm = (mv && shi > slo) ? (((1u << shi) - 1u) & ~((1u << slo) - 1u)) : 0u;
-    unsigned vm = 0;
-    for (int r = rlo; r < rhi; ++r) vm |= sm << (r * p.S);
-    vmask[i] = vm;
-    if (UPS) {
-      pixbase[i] = b * p.Hi * p.Wi; hb[i] = h0; wb[i] = w0;
-      xrow[i] = nullptr;
-    } else {
-      xrow[i] = reinterpret_cast<const char*>(p.x) + ((long)(b * p.Hi * p.Wi + h0 * p.Wi + w0) * p.ldx + cl * 8) * 2;
-    }
-  }
   const char* wptr[WP];
   int winc[WP];
-#pragma unroll
-  for (int i = 0; i < WP; ++i) {
-    const int n = n0 + lrow + i * RPP;
-    const bool nv = n < p.N;
-    wptr[i] = nv ? reinterpret_cast<const char*>(p.w + (size_t)n * p.ldw + (size_t)kbeg * BK + cl * 8) : zero;
-    winc[i] = nv ? BK * 2 : 0;
-  }
   const int tapsteps = p.Cin >> 6;
   int st_c = kbeg % tapsteps, st_r = (kbeg / tapsteps) / p.S, st_s = (kbeg / tapsteps) % p.S;   // next K-step to issue
+  if (do_load && !(p.dbg & 64)) {
+    const int Hv = UPS ? 2 * p.Hi : p.Hi, Wv = UPS ? 2 * p.Wi : p.Wi;
+    const int R = p.K / (p.S * p.Cin);
+    const bool linear = !UPS && p.K == p.Cin && p.stride == 1 && p.pad == 0;   // Linear / conv1x1: row m IS pixel m
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int m = m0 + lrow + i * RPP;
+      const bool mv = m < p.M;
+      if (linear) {
+        vmask[i] = (mv && !(p.dbg & 1)) ? 1u : 0u;
+        xrow[i] = reinterpret_cast<const char*>(p.x) + ((long)m * p.ldx + cl * 8) * 2;
+        continue;
+      }
+      const int mm = mv ? m : 0;
+      const int b = mm / p.HoWo;
+      const int rem = mm - b * p.HoWo;
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
+      // taps inside the image: rows rlo..rhi-1, columns slo..shi-1
+      const int rlo = max(0, -h0), rhi = min(R, Hv - h0), slo = max(0, -w0), shi = min(p.S, Wv - w0);
+      const unsigned sm = (mv && shi > slo && !(p.dbg & 1)) ? (((1u << shi) - 1u) & ~((1u << slo) - 1u)) : 0u;
+      unsigned vm = 0;
+      for (int r = rlo; r < rhi; ++r) vm |= sm << (r * p.S);
+      vmask[i] = vm;
+      if (UPS) {
+        pixbase[i] = b * p.Hi * p.Wi; hb[i] = h0; wb[i] = w0;
+        xrow[i] = nullptr;
+      } else {
+        xrow[i] = reinterpret_cast<const char*>(p.x) + ((long)(b * p.Hi * p.Wi + h0 * p.Wi + w0) * p.ldx + cl * 8) * 2;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+      const int n = n0 + lrow + i * RPP;
+      const bool nv = n < p.N && !(p.dbg & 2);
+      wptr[i] = nv ? reinterpret_cast<const char*>(p.w + (size_t)n * p.ldw + (size_t)kbeg * BK + cl * 8) : zero;
+      winc[i] = nv ? BK * 2 : 0;
+    }
+  }
 
-  // issue the DMAs of the NEXT K-step into ring slot `slot` (every lane issues exactly L of them)
+  // issue the DMAs of the NEXT K-step into ring slot `slot` (every loading lane issues exactly L of them)
   auto issue = [&](int slot) {
     const int tapbit = st_r * p.S + st_s;
     char* xs = smem + slot * STAGE + wave_u * 1024;
@@ -234,6 +262,30 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KP p) {
       if (++st_s == p.S) { st_s = 0; ++st_r; }
     }
   };
+  // retire the DMAs of K-step `it`: all but the (newer) steps still allowed in flight
+  auto retire = [&](int it) {
+    const int ahead = min(PF - 1, nk - 1 - it);
+    if (ahead >= 3) wait_vmcnt<3 * L>();
+    else if (ahead == 2) wait_vmcnt<2 * L>();
+    else if (ahead == 1) wait_vmcnt<L>();
+    else wait_vmcnt<0>();
+  };
+
+  if constexpr (WS) {
+    if (!do_mma) {                         // ---- loader waves
+      if (nk > 0) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s)
+          if (s < nk) issue(s);
+        for (int it = 0; it < nk; ++it) {
+          retire(it);
+          __builtin_amdgcn_s_barrier();
+          if (it + PF < nk && !(p.dbg & 8)) issue((it + PF) % STAGES);
+        }
+      }
+      return;
+    }
+  }
 
   f32x4 acc[NI][MI];
 #pragma unroll
@@ -252,41 +304,128 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const KP p) {
     bpre[i] = (use_bpre && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  if (nk > 0) {
+  // One K-step of MFMAs.  hipcc waits lgkmcnt(0) before the first MFMA after ANY group of LDS reads in this kernel (it
+  // never emits a partial count here), and left alone it keeps a minimal fragment set: four full LDS round trips per
+  // K-step in front of ~20 MFMAs (measured 700 clocks per step for 320 clocks of MFMA).  So on tiles with room for two
+  // fragment sets the reads are inline asm (invisible to the compiler's wait insertion) with hand-counted waits: all reads
+  // of the step are issued, lgkmcnt(NI+MI) releases the 32-deep half 0 (LDS returns in order), its MFMAs run while half 1
+  // lands.  sched_barrier(0) after each wait keeps hipcc from hoisting MFMAs above it.
+  constexpr bool DB = (NI + MI) * 8 + NI * MI * 4 <= 200;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int swl = (frow >> 1) & 7;                      // == (row >> 1) & 7: every fragment row is frow + multiple of 16
+  const unsigned xa0 = lds0 + (wm * TM + frow) * 128 + ((fq ^ swl) << 4), xa1 = lds0 + (wm * TM + frow) * 128 + (((4 + fq) ^ swl) << 4);
+  const unsigned wa0 = xa0 + XBYTES + (wn * TN - wm * TM) * 128, wa1 = xa1 + XBYTES + (wn * TN - wm * TM) * 128;
+  auto read_half = [&](const char* xs, const char* wsm, int kk, f16x8 (&wf)[NI], f16x8 (&xf)[MI]) {
 #pragma unroll
-    for (int s = 0; s < PF; ++s)
-      if (s < nk) issue(s);
-    for (int it = 0; it < nk; ++it) {
-      // retire the DMAs of K-step `it`: all but the (newer) steps still allowed in flight
-      const int ahead = min(PF - 1, nk - 1 - it);
-      if (ahead >= 2) wait_vmcnt<2 * L>();
-      else if (ahead == 1) wait_vmcnt<L>();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();      // step `it` visible to every wave; everyone is done reading slot (it-1)%STAGES
-      if (it + PF < nk) issue((it + PF) % STAGES);
+    for (int i = 0; i < NI; ++i) {
+      const int row = wn * TN + i * 16 + frow;
+      wf[i] = *reinterpret_cast<const f16x8*>(wsm + row * 128 + swz_chunk<64>(row, kk * 4 + fq) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const int row = wm * TM + j * 16 + frow;
+      xf[j] = *reinterpret_cast<const f16x8*>(xs + row * 128 + swz_chunk<64>(row, kk * 4 + fq) * 16);
+    }
+  };
+  auto mma_half = [&](const f16x8 (&wf)[NI], const f16x8 (&xf)[MI]) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < MI; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+  };
+  auto compute = [&](int it) {
+    if constexpr (DB) {
+      const unsigned sb = (it % STAGES) * STAGE;
+      f16x8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
+      static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wf0[I.value], wa0 + sb); });
+      static_for<MI>([&](auto J) { lds_read128<J.value * 2048>(xf0[J.value], xa0 + sb); });
+      static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wf1[I.value], wa1 + sb); });
+      static_for<MI>([&](auto J) { lds_read128<J.value * 2048>(xf1[J.value], xa1 + sb); });
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NI + MI) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(wf0, xf0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(wf1, xf1);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
       const char* xs = smem + (it % STAGES) * STAGE;
       const char* wsm = xs + XBYTES;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         f16x8 wf[NI], xf[MI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const int row = wn * TN + i * 16 + frow;
-          wf[i] = *reinterpret_cast<const f16x8*>(wsm + row * 128 + swz_chunk<64>(row, kk * 4 + fq) * 16);
+        read_half(xs, wsm, kk, wf, xf);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(wf, xf);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  if (nk > 0) {
+    if constexpr (WS) {                    // ---- MFMA waves
+      // retire every scalar (kernel-argument) load here: while one may be pending the compiler's wait-count pass has to
+      // assume out-of-order LGKM returns and turns each partial lgkmcnt(N) in the loop into lgkmcnt(0)
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      if constexpr (DB) {
+        // Rotated loop: barrier `it+1` and the half-0 reads of step it+1 are issued BEFORE the half-1 MFMAs of step it,
+        // the half-1 reads of step it+1 right after them, so every LDS round trip and the barrier hide under 32-deep
+        // halves of MFMAs.  A wave reaches barrier it+1 only after lgkmcnt(0), i.e. with all its reads of step `it` in
+        // registers, which is what allows the loaders to refill that slot.  Register sets are rewritten only after the
+        // MFMAs reading them have issued (an LDS return is >60 clocks away, an MFMA reads its operands at issue).
+        f16x8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
+        auto reads0 = [&](unsigned sb) {
+          if (p.dbg & 16) return;
+          static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wf0[I.value], wa0 + sb); });
+          static_for<MI>([&](auto J) { lds_read128<J.value * 2048>(xf0[J.value], xa0 + sb); });
+        };
+        auto reads1 = [&](unsigned sb) {
+          if (p.dbg & 16) return;
+          static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wf1[I.value], wa1 + sb); });
+          static_for<MI>([&](auto J) { lds_read128<J.value * 2048>(xf1[J.value], xa1 + sb); });
+        };
+        __builtin_amdgcn_s_barrier();        // step 0 visible
+        reads0(0);
+        reads1(0);
+        for (int it = 0; it < nk; ++it) {
+          const bool more = it + 1 < nk;
+          const unsigned sbn = ((it + 1) % STAGES) * STAGE;
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NI + MI) : "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(p.dbg & 4)) mma_half(wf0, xf0);
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) {
+            __builtin_amdgcn_s_barrier();    // step it+1 visible; every MFMA wave holds step `it` in registers
+            reads0(sbn);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(p.dbg & 4)) mma_half(wf1, xf1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) reads1(sbn);
         }
-#pragma unroll
-        for (int j = 0; j < MI; ++j) {
-          const int row = wm * TM + j * 16 + frow;
-          xf[j] = *reinterpret_cast<const f16x8*>(xs + row * 128 + swz_chunk<64>(row, kk * 4 + fq) * 16);
+      } else {
+        for (int it = 0; it < nk; ++it) {
+          __builtin_amdgcn_s_barrier();      // step `it` visible (its loaders retired it before arriving here)
+          if (!(p.dbg & 4)) compute(it);
         }
+      }
+    } else {
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-          for (int j = 0; j < MI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      for (int s = 0; s < PF; ++s)
+        if (s < nk) issue(s);
+      for (int it = 0; it < nk; ++it) {
+        retire(it);
+        __builtin_amdgcn_s_barrier();      // step `it` visible to every wave; everyone is done reading slot (it-1)%STAGES
+        if (it + PF < nk) issue((it + PF) % STAGES);
+        compute(it);
       }
     }
   }
+  if (p.dbg & 32) return;
   epilogue<NI, MI, TM, TN>(p, acc, m0, n0, wm, wn, frow, fq, z, bpre, use_bpre);
 }
 
@@ -505,8 +644,17 @@ static const TileCfg kTiles[] = {
     {128, 64, 32, 2, TK_GENERIC, 0.85f, 3, "conv_gemm_kernel<128,64,32,true>"},
     {64, 64, 32, 2, TK_GENERIC, 0.65f, 4, "conv_gemm_kernel<64,64,32,true>"},
     {256, 128, 64, 3, TK_DMA, 1.25f, 1, "conv_gemm_dma_kernel<256,128,3>"},
+    // 160-wide weight panels: the channel counts of this model are multiples of 320, and what bounds these kernels is the
+    // bytes a CU has to take in per K-step, so the tile menu is built to hit 256 equal workgroups
+    {64, 160, 64, 3, TK_DMA, 0.90f, 1, "conv_gemm_dma_kernel<64,160,3>"},
+    {128, 160, 64, 3, TK_DMA, 1.10f, 1, "conv_gemm_dma_kernel<128,160,3>"},
+    {256, 160, 64, 3, TK_DMA, 1.30f, 1, "conv_gemm_dma_kernel<256,160,3>"},
+    {32, 160, 64, 4, TK_DMA, 0.60f, 2, "conv_gemm_dma_kernel<32,160,4>"},
+    {64, 160, 64, 5, TK_DMA, 0.90f, 1, "conv_gemm_dma_kernel<64,160,5>"},
+    {128, 160, 64, 4, TK_DMA, 1.10f, 1, "conv_gemm_dma_kernel<128,160,4>"},
+    {128, 64, 64, 5, TK_DMA, 0.85f, 1, "conv_gemm_dma_kernel<128,64,5>"},
 };
-static const int kNumTiles = 6;
+static const int kNumTiles = 13;
 static const int kNumCU = 256;
 
 struct Plan { int tile; int splitk; int nk; int tiles_m, tiles_n; };
@@ -544,28 +692,29 @@ static Plan make_plan(const ConvGemm& p) {
     const int tmn = cdiv(p.M, c.bm), tnn = cdiv(p.N, c.bn);
     const int tiles = tmn * tnn;
     const int nk = cdiv(p.K, c.bk);
-    const int slots = kNumCU * c.wg_per_cu;
-    // candidate split-K factors: 1 and whatever fills the chip once
+    // candidate split-K factors: 1 and whatever gives every CU one or two workgroups
     int cands[3] = {1, 0, 0};
     int ncand = 1;
-    if (tiles < slots && nk >= 8) {
-      int sk = slots / tiles;
-      if (sk > nk / 4) sk = nk / 4;
-      if (sk > 16) sk = 16;
-      if (sk >= 2) cands[ncand++] = sk;
-      if (sk >= 4) cands[ncand++] = sk / 2;
+    if (tiles < kNumCU && nk >= 8) {
+      for (int fill = 1; fill <= 2; ++fill) {
+        int sk = fill * kNumCU / tiles;
+        if (sk > nk / 4) sk = nk / 4;
+        if (sk > 16) sk = 16;
+        if (sk >= 2 && sk != cands[ncand - 1]) cands[ncand++] = sk;
+      }
     }
     if (force_sk > 0) { cands[0] = force_sk > nk ? nk : force_sk; ncand = 1; }
     for (int ci = 0; ci < ncand; ++ci) {
       int sk = cands[ci];
       const int per = cdiv(nk, sk);
       sk = cdiv(nk, per);
-      // crude time model (arbitrary units): waves of workgroups x K-steps per workgroup x cost per step,
-      // plus fixed prologue/epilogue and the split-K slab traffic
-      const float rounds = (float)cdiv(tiles * sk, slots);
-      const float step_cost = (float)(c.bm * c.bn) / (128.f * 128.f) / c.weight;
-      float tcost = rounds * (per * step_cost + 3.0f);
-      if (sk > 1) tcost += 2.0f + (float)sk * p.M * p.N * 8.0f / 4.0e6f;   // write + read of fp32 partials
+      // time model in clocks: a CU takes in ~28 B/clk through the vector-memory path whatever
+      // the source, so a K-step of a workgroup costs max((bm+bn) * 128 B / 28, MFMA time of the tile); the workgroups
+      // are spread over 256 CUs; ~9k clocks of launch / prologue / epilogue per kernel
+      const float rounds = (float)cdiv(tiles * sk, kNumCU);
+      const float step_clk = fmaxf((float)(c.bm + c.bn) * 4.57f, (float)(c.bm * c.bn) / 31.8f);
+      float tcost = 9000.f + rounds * ((float)per * step_clk + 1500.f);
+      if (sk > 1) tcost += 8000.f + ((float)sk + 1.f) * p.M * p.N * 4.0f / 1700.f;   // reduce launch + fp32 slabs at ~4 TB/s
       if (tcost < best_t) { best_t = tcost; best = Plan{t, sk, nk, tmn, tnn}; }
     }
   }
@@ -580,15 +729,32 @@ size_t conv_gemm_workspace_bytes(const ConvGemm& p) {
 const char* conv_gemm_kernel_name(const ConvGemm& p) { return kTiles[make_plan(p).tile].name; }
 
 template <typename K>
-static int launch_k(K kernel, int smem, bool* attr_done, const KP& kp, int tiles, hipStream_t stream) {
+static int launch_k(K kernel, int smem, bool* attr_done, const KP& kp, int tiles, hipStream_t stream, int threads = 256) {
   if (!*attr_done) {
     SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     *attr_done = true;
   }
   dim3 grid(tiles, 1, kp.splitk);
-  hipLaunchKernelGGL(kernel, grid, dim3(256), smem, stream, kp);
+  hipLaunchKernelGGL(kernel, grid, dim3(threads), smem, stream, kp);
   SDEO_HIP(hipGetLastError());
   return 0;
+}
+
+static int g_ws = -1;     // wave-specialised variant: -1 = SDEO_GEMM_WS env (default on)
+static bool use_ws() {
+  if (g_ws < 0) { const char* e = getenv("SDEO_GEMM_WS"); g_ws = e ? atoi(e) : 1; }
+  return g_ws != 0;
+}
+
+template <int BM, int BN, int ST>
+static int launch_dma(int ups, const KP& kp, int tiles, hipStream_t stream) {
+  static bool done[4] = {false, false, false, false};
+  constexpr int smem = ST * (BM + BN) * 128;
+  if (use_ws())
+    return ups ? launch_k(&conv_gemm_dma_kernel<BM, BN, ST, true, true>, smem, &done[3], kp, tiles, stream, 512)
+               : launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, true>, smem, &done[2], kp, tiles, stream, 512);
+  return ups ? launch_k(&conv_gemm_dma_kernel<BM, BN, ST, true, false>, smem, &done[1], kp, tiles, stream)
+             : launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, false>, smem, &done[0], kp, tiles, stream);
 }
 
 int conv_gemm(const ConvGemm& p, hipStream_t stream) {
@@ -628,6 +794,7 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
     const double xb = (double)p.M * p.Cin * 2.0 * (p.R * p.S > 1 ? 1.3 : 1.0), wb = (double)p.N * p.K * 2.0;
     const double cost_n_fast = xb + 8.0 * wb;
     const double cost_m_fast = (pl.tiles_n < 8 ? pl.tiles_n : 8) * xb + wb * (pl.tiles_n < 8 ? 1.6 : 1.0);
+    { static const int dbg = [] { const char* e = getenv("SDEO_DBG_GEMM"); return e ? atoi(e) : 0; }(); kp.dbg = dbg; }
     kp.n_fastest = g_force_order >= 0 ? g_force_order : (cost_n_fast < cost_m_fast ? 1 : 0);
   }
   if (pl.splitk > 1) {
@@ -636,27 +803,21 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
                p.workspace_bytes, need);
   }
   const int tiles = pl.tiles_m * pl.tiles_n;
-  static bool done[10] = {false, false, false, false, false, false, false, false, false, false};
   int rc = 0;
   switch (pl.tile) {
-    case 0:
-      rc = p.ups ? launch_k(&conv_gemm_dma_kernel<128, 128, 3, true>, 3 * (128 + 128) * 128, &done[6], kp, tiles, stream)
-                 : launch_k(&conv_gemm_dma_kernel<128, 128, 3, false>, 3 * (128 + 128) * 128, &done[0], kp, tiles, stream);
-      break;
-    case 1:
-      rc = p.ups ? launch_k(&conv_gemm_dma_kernel<128, 64, 3, true>, 3 * (128 + 64) * 128, &done[7], kp, tiles, stream)
-                 : launch_k(&conv_gemm_dma_kernel<128, 64, 3, false>, 3 * (128 + 64) * 128, &done[1], kp, tiles, stream);
-      break;
-    case 2:
-      rc = p.ups ? launch_k(&conv_gemm_dma_kernel<64, 64, 4, true>, 4 * (64 + 64) * 128, &done[8], kp, tiles, stream)
-                 : launch_k(&conv_gemm_dma_kernel<64, 64, 4, false>, 4 * (64 + 64) * 128, &done[2], kp, tiles, stream);
-      break;
-    case 3: rc = launch_k(&conv_gemm_kernel<128, 64, 32, true>, 2 * (128 + 64) * 64, &done[3], kp, tiles, stream); break;
-    case 4: rc = launch_k(&conv_gemm_kernel<64, 64, 32, true>, 2 * (64 + 64) * 64, &done[4], kp, tiles, stream); break;
-    case 5:
-      rc = p.ups ? launch_k(&conv_gemm_dma_kernel<256, 128, 3, true>, 3 * (256 + 128) * 128, &done[9], kp, tiles, stream)
-                 : launch_k(&conv_gemm_dma_kernel<256, 128, 3, false>, 3 * (256 + 128) * 128, &done[5], kp, tiles, stream);
-      break;
+    case 0: rc = launch_dma<128, 128, 3>(p.ups, kp, tiles, stream); break;
+    case 1: rc = launch_dma<128, 64, 3>(p.ups, kp, tiles, stream); break;
+    case 2: rc = launch_dma<64, 64, 4>(p.ups, kp, tiles, stream); break;
+    case 3: { static bool d = false; rc = launch_k(&conv_gemm_kernel<128, 64, 32, true>, 2 * (128 + 64) * 64, &d, kp, tiles, stream); break; }
+    case 4: { static bool d = false; rc = launch_k(&conv_gemm_kernel<64, 64, 32, true>, 2 * (64 + 64) * 64, &d, kp, tiles, stream); break; }
+    case 5: rc = launch_dma<256, 128, 3>(p.ups, kp, tiles, stream); break;
+    case 6: rc = launch_dma<64, 160, 3>(p.ups, kp, tiles, stream); break;
+    case 7: rc = launch_dma<128, 160, 3>(p.ups, kp, tiles, stream); break;
+    case 8: rc = launch_dma<256, 160, 3>(p.ups, kp, tiles, stream); break;
+    case 9: rc = launch_dma<32, 160, 4>(p.ups, kp, tiles, stream); break;
+    case 10: rc = launch_dma<64, 160, 5>(p.ups, kp, tiles, stream); break;
+    case 11: rc = launch_dma<128, 160, 4>(p.ups, kp, tiles, stream); break;
+    case 12: rc = launch_dma<128, 64, 5>(p.ups, kp, tiles, stream); break;
     default: return fail("conv_gemm: bad tile %d", pl.tile);
   }
   if (rc) return rc;
@@ -709,7 +870,7 @@ int conv_gemm_autotune(const ConvGemm& p, hipStream_t stream) {
   if (!is_fast(p) || g_force_tile >= 0 || g_force_splitk > 0) return 0;
   const ShapeKey key = key_of(p);
   if (g_tuned.count(key)) return 0;
-  static const int tiles[] = {0, 1, 2, 5};
+  static const int tiles[] = {0, 1, 2, 5, 6, 7, 8, 9};
   static const int sks[] = {1, 2, 3, 4, 6, 8, 12, 16};
   hipEvent_t a, b;
   SDEO_HIP(hipEventCreate(&a));

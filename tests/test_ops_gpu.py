@@ -139,6 +139,31 @@ def test_conv2d_epilogue(ops):
     assert_close(y.permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3, what="conv epilogue")
 
 
+DMA_TILES = [0, 1, 2, 5, 6, 7, 8, 9]     # kTiles indices of conv_gemm_dma_kernel<BM,BN,STAGES> in csrc/conv_gemm.hip
+
+
+@pytest.mark.parametrize("tile", DMA_TILES)
+@pytest.mark.parametrize("sk", [1, 3])
+def test_conv2d_every_dma_tile(ops, tile, sk):
+    """every LDS-DMA tile shape (forced), with and without split-K, on ragged M / N and on the folded upsample"""
+    import ctypes as C
+    from stablediffusioneo_amd import _lib
+    lib = _lib.load()
+    try:
+        lib.sdeo_debug_force_gemm_plan(C.c_int(tile), C.c_int(sk))
+        for (n, cin, h, w, cout, ups) in [(2, 128, 13, 11, 328, 0), (1, 64, 9, 10, 160, 1), (2, 192, 8, 8, 72, 0)]:
+            x = h16(randn((n, cin, h, w), 230 + cin))
+            wt = h16(randn((cout, cin, 3, 3), 231) * (1.0 / (cin * 9)) ** 0.5)
+            bias = 0.1 * randn((cout,), 232)
+            xin = F.interpolate(x.float(), scale_factor=2, mode="nearest") if ups else x.float()
+            ref = F.conv2d(xin, wt.float(), bias, padding=1)
+            y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), wt.permute(0, 2, 3, 1).contiguous().to(DEV),
+                                bias.to(DEV), upsample2x=bool(ups))
+            assert_close(y.permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3, what=f"tile {tile} sk {sk} conv {(n, cin, h, w, cout, ups)}")
+    finally:
+        lib.sdeo_debug_force_gemm_plan(C.c_int(-1), C.c_int(0))
+
+
 def test_krsc_transform(ops):
     w = randn((24, 4, 3, 3), 220)
     y = ops.krsc_from_oihw(w.to(DEV), 8).cpu()
