@@ -50,7 +50,9 @@ struct KP {
   float scale;
   int nk, nk_per_split, splitk;
   int tiles_m, tiles_n;
-  int dbg;           // SDEO_DBG_GEMM (measurement only): bit 0 = activation DMAs read the zero page, bit 1 = weight DMAs do
+  // SDEO_DBG_GEMM (measurement only, results are wrong): 1 = activation DMAs read the zero page, 2 = weight DMAs do,
+  // 4 = no MFMAs, 8 = no DMAs after the prologue, 16 = no fragment reads, 32 = no epilogue
+  int dbg;
   int n_fastest;     // tile order inside an XCD's contiguous run: 1 = all N tiles of an M tile are neighbours
 };
 
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
   int winc[WP];
   const int tapsteps = p.Cin >> 6;
   int st_c = kbeg % tapsteps, st_r = (kbeg / tapsteps) / p.S, st_s = (kbeg / tapsteps) % p.S;   // next K-step to issue
-  if (do_load && !(p.dbg & 64)) {
+  if (do_load) {
     const int Hv = UPS ? 2 * p.Hi : p.Hi, Wv = UPS ? 2 * p.Wi : p.Wi;
     const int R = p.K / (p.S * p.Cin);
     const bool linear = !UPS && p.K == p.Cin && p.stride == 1 && p.pad == 0;   // Linear / conv1x1: row m IS pixel m
@@ -209,7 +211,9 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
       const int rlo = max(0, -h0), rhi = min(R, Hv - h0), slo = max(0, -w0), shi = min(p.S, Wv - w0);
       const unsigned sm = (mv && shi > slo && !(p.dbg & 1)) ? (((1u << shi) - 1u) & ~((1u << slo) - 1u)) : 0u;
       unsigned vm = 0;
-      for (int r = rlo; r < rhi; ++r) vm |= sm << (r * p.S);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)          // R <= 4 (checked on the host): straight-line selects instead of a divergent loop
+        if (r >= rlo && r < rhi) vm |= sm << (r * p.S);
       vmask[i] = vm;
       if (UPS) {
         pixbase[i] = b * p.Hi * p.Wi; hb[i] = h0; wb[i] = w0;
@@ -764,6 +768,7 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
   SDEO_CHECK(p.Cin % 8 == 0 && p.ldx % 8 == 0 && p.ldw % 8 == 0, "conv_gemm: Cin=%d ldx=%d ldw=%d must be multiples of 8",
              p.Cin, p.ldx, p.ldw);
   SDEO_CHECK(p.K == p.R * p.S * p.Cin, "conv_gemm: K=%d != R*S*Cin=%d", p.K, p.R * p.S * p.Cin);
+  SDEO_CHECK(p.R >= 1 && p.R <= 4 && p.S >= 1 && p.S <= 4, "conv_gemm: filter %dx%d unsupported (1..4)", p.R, p.S);
   SDEO_CHECK(p.ldw >= p.K, "conv_gemm: ldw=%d < K=%d", p.ldw, p.K);
   SDEO_CHECK(p.M == p.B * p.Ho * p.Wo, "conv_gemm: M=%d != B*Ho*Wo=%d", p.M, p.B * p.Ho * p.Wo);
   SDEO_CHECK(p.ldy % 4 == 0 && p.ldy >= p.N, "conv_gemm: ldy=%d", p.ldy);

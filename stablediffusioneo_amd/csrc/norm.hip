@@ -230,15 +230,193 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(f16* __restrict__ y, int 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Single-launch GroupNorm for tensors whose per-(image, group set) slice fits in one workgroup's LDS.
+// Every kernel on this chip costs ~4 us of launch + dependent round trips whatever its size (DESIGN.md
+// section 10), so below the 64x64 level the two-launch path above is mostly fixed cost.
+// grid (channel parts, B); a part is the smallest run of channel vectors that covers whole groups
+// (lcm(cpg, 8) channels).  The slice is pulled into LDS by LDS-DMA (every piece in flight at once, no
+// registers), thread t owning vector t of each NT-vector sweep; statistics are reduced deterministically
+// (per-thread partials -> LDS -> one wave per (vector, slot) column in a fixed order); the second pass
+// normalises from LDS.  A vector of 8 channels spans at most two groups ("slots"), checked on the host.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(NT) void gn_fused_kernel(f16* __restrict__ y, int ldy, const f16* __restrict__ x, int ldx,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int HW,
+                                                      int cpg, int nvw, int nsweep, float eps, int with_silu) {
+  extern __shared__ __attribute__((aligned(16))) char gsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int P = NT / nvw;                       // pixel rows per sweep
+  const int v = tid % nvw, prow = tid / nvw;
+  const bool active = prow < P;
+  const int part = blockIdx.x, b = blockIdx.y;
+  const int c0 = (part * nvw + v) * 8;          // parts start on a group boundary
+  char* slice = gsm;                                                                  // [nsweep][NT] 16-byte vectors
+  float2* part_sq = reinterpret_cast<float2*>(gsm + (size_t)nsweep * NT * 16);        // [2 * nvw][P]
+  float2* tot = part_sq + (size_t)2 * nvw * P;                                        // [2 * nvw]
+  float* s_mean = reinterpret_cast<float*>(tot + 2 * nvw);                            // [groups per part]
+  float* s_rstd = s_mean + 32;
+
+  const f16* xb = x + ((size_t)b * HW) * ldx + c0;
+  f16* yb = y + ((size_t)b * HW) * ldy + c0;
+  for (int k = 0; k < nsweep; ++k) {
+    const int pix = prow + k * P;
+    // lanes without a pixel fetch a valid dummy (the first pixel of their vector); they are masked below
+    const f16* src = (active && pix < HW) ? xb + (size_t)pix * ldx : x + c0 % 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(slice + (size_t)k * NT * 16 + wave_u * 1024), 16, 0, 0);
+  }
+  f32x4 gm[2], bt[2];
+  gm[0] = *reinterpret_cast<const f32x4*>(gamma + c0);
+  gm[1] = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
+  bt[0] = *reinterpret_cast<const f32x4*>(beta + c0);
+  bt[1] = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // own DMAs landed; each thread only reads back its own vectors
+
+  const int g_lo = (v * 8) / cpg;                 // group (inside the part) of this vector's first channel
+  const int nb = (g_lo + 1) * cpg - v * 8;        // channels of the vector that belong to g_lo (>= 1; may exceed 8)
+  float sj[8], qj[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sj[j] = 0.f; qj[j] = 0.f; }
+  const char* mine = slice + (size_t)tid * 16;
+  for (int k = 0; k < nsweep; ++k) {
+    if (active && prow + k * P < HW) {
+      const f16x8 xv = *reinterpret_cast<const f16x8*>(mine + (size_t)k * NT * 16);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)xv[j];
+        sj[j] += f;
+        qj[j] += f * f;
+      }
+    }
+  }
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < nb) { s0 += sj[j]; q0 += qj[j]; }
+    else { s1 += sj[j]; q1 += qj[j]; }
+  }
+  if (active) {
+    part_sq[(size_t)(v * 2) * P + prow] = make_float2(s0, q0);
+    part_sq[(size_t)(v * 2 + 1) * P + prow] = make_float2(s1, q1);
+  }
+  __syncthreads();
+  for (int pair = wave; pair < 2 * nvw; pair += NT / 64) {
+    float ts = 0.f, tq = 0.f;
+    const float2* col = part_sq + (size_t)pair * P;
+    for (int e = lane; e < P; e += 64) { ts += col[e].x; tq += col[e].y; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      ts += __shfl_xor(ts, off, 64);
+      tq += __shfl_xor(tq, off, 64);
+    }
+    if (lane == 0) tot[pair] = make_float2(ts, tq);
+  }
+  __syncthreads();
+  const int gpw = nvw * 8 / cpg;                  // groups in this part
+  if (tid < gpw) {
+    float ts = 0.f, tq = 0.f;
+    for (int vv = 0; vv < nvw; ++vv) {
+      const int gl = (vv * 8) / cpg;
+      if (gl == tid) { ts += tot[vv * 2].x; tq += tot[vv * 2].y; }
+      if (gl + 1 == tid) { ts += tot[vv * 2 + 1].x; tq += tot[vv * 2 + 1].y; }
+    }
+    const float inv = 1.0f / ((float)cpg * (float)HW);
+    const float mean = ts * inv;
+    float var = tq * inv - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    s_mean[tid] = mean;
+    s_rstd[tid] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  if (!active) return;
+  float a[8], bb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int g = j < nb ? g_lo : g_lo + 1;
+    const float sc = s_rstd[g] * gm[j >> 2][j & 3];
+    a[j] = sc;
+    bb[j] = bt[j >> 2][j & 3] - s_mean[g] * sc;
+  }
+  for (int k = 0; k < nsweep; ++k) {
+    const int pix = prow + k * P;
+    if (pix < HW) {
+      const f16x8 xv = *reinterpret_cast<const f16x8*>(mine + (size_t)k * NT * 16);
+      f16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f = (float)xv[j] * a[j] + bb[j];
+        if (with_silu) f = silu_f(f);
+        o[j] = (f16)f;
+      }
+      *reinterpret_cast<f16x8*>(yb + (size_t)pix * ldy) = o;
+    }
+  }
+}
+
+// vectors per part of the single-launch path (0 = not applicable): lcm(cpg, 8) / 8, every vector within two groups
+static int gn_fused_vecs(int C, int cpg) {
+  if (cpg < 4) return 0;
+  int l = cpg;
+  while (l % 8) l += cpg;
+  const int nvw = l / 8;
+  if (nvw > 16 || (C / 8) % nvw) return 0;
+  for (int v = 0; v < nvw; ++v)
+    if ((v * 8 + 7) / cpg - (v * 8) / cpg > 1) return 0;
+  return nvw;
+}
+
+static const size_t kGnFusedLdsCap = 144 * 1024;
+
+template <int NT>
+static size_t gn_fused_smem(int HW, int nvw) {
+  const int P = NT / nvw, nsweep = cdiv(HW, P);
+  return (size_t)nsweep * NT * 16 + ((size_t)2 * nvw * P + 2 * nvw) * sizeof(float2) + 64 * sizeof(float);
+}
+
+template <int NT>
+static int launch_gn_fused(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const float* beta, int B, int HW, int C,
+                           int cpg, int nvw, float eps, int with_silu, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)kGnFusedLdsCap));
+    attr_done = true;
+  }
+  const int P = NT / nvw, nsweep = cdiv(HW, P);
+  hipLaunchKernelGGL((gn_fused_kernel<NT>), dim3((C / 8) / nvw, B), dim3(NT), gn_fused_smem<NT>(HW, nvw), stream, y, ldy, x, ldx,
+                     gamma, beta, HW, cpg, nvw, nsweep, eps, with_silu);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
 int groupnorm_nhwc(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const float* beta, int B, int HW, int C,
                    int groups, float eps, int with_silu, float* partials, hipStream_t stream) {
   SDEO_CHECK(y && x && gamma && beta && partials, "groupnorm: null operand");
   SDEO_CHECK(B > 0 && HW > 0 && C > 0, "groupnorm: empty tensor");
   SDEO_CHECK(groups > 0 && groups <= 64 && C % groups == 0, "groupnorm: C=%d not divisible into %d groups", C, groups);
   SDEO_CHECK(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "groupnorm: C=%d ldx=%d ldy=%d must be multiples of 8", C, ldx, ldy);
+  const int cpg = C / groups;
+  {
+    static const int two_pass = [] { const char* e = getenv("SDEO_GN_TWO_PASS"); return e ? atoi(e) : 0; }();
+    const int nvw = two_pass ? 0 : gn_fused_vecs(C, cpg);
+    if (nvw > 0) {
+      // small slices: 256 threads (more workgroups per CU); otherwise 1024 threads, if the slice fits in LDS
+      // Measured (tools/small_bench.py): one launch wins up to 16x16 pixels (6.1 vs 9.0 us at 8x8, 8.4 vs 9.5 at 16x16);
+      // from 32x32 on, the many-workgroup two-launch path is faster than one workgroup per part (9.9 vs 12.3 us).
+      // SDEO_GN_FUSED_MAX_HW overrides the crossover for measurements.
+      static const int max_hw = [] { const char* e = getenv("SDEO_GN_FUSED_MAX_HW"); return e ? atoi(e) : 256; }();
+      if (HW <= max_hw) {
+        if (cdiv(HW, 256 / nvw) <= 8 && gn_fused_smem<256>(HW, nvw) <= kGnFusedLdsCap)
+          return launch_gn_fused<256>(y, ldy, x, ldx, gamma, beta, B, HW, C, cpg, nvw, eps, with_silu, stream);
+        if (cdiv(HW, 1024 / nvw) <= 60 && gn_fused_smem<1024>(HW, nvw) <= kGnFusedLdsCap)
+          return launch_gn_fused<1024>(y, ldy, x, ldx, gamma, beta, B, HW, C, cpg, nvw, eps, with_silu, stream);
+      }
+    }
+  }
   const int nvb = gn_vec_per_block(C, groups);
   SDEO_CHECK(nvb > 0, "groupnorm: unsupported channel split C=%d groups=%d", C, groups);
-  const int cpg = C / groups;
   const int parts = (C / 8) / nvb;
   // Both kernels are chains of dependent memory round trips (~0.5 us each on this chip), so the chunking is chosen to
   // give every thread ONE batch of independent loads: 4 pixels per thread in apply (prefetched before the statistics

@@ -2,6 +2,7 @@
 stablediffusioneo_amd/tuned_plans_gfx950.json (copy it back from gpurun_out/ and commit it).
 
     python tools/tune_plans.py            # on the GPU box; writes gpurun_out/tuned_plans_gfx950.json
+    SDEO_TUNED_PLANS=0 python tools/tune_plans.py     # ignore the committed table and re-measure every shape
 """
 import json
 import os
