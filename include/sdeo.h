@@ -89,6 +89,12 @@ int sdeo_layernorm_f16(void* y, const void* x, const float* gamma, const float* 
 int sdeo_attention_f16(void* o, int ldo, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int b,
                        int heads, int tq, int tk, int tk_stride, int vt_batch_stride, int d, float scale, void* stream);
 
+/* as sdeo_attention_f16 with the causal mask of the CLIP text transformer: key j is masked for query t when j > t
+ * (needs tq == tk) */
+int sdeo_attention_causal_f16(void* o, int ldo, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int b,
+                              int heads, int tq, int tk, int tk_stride, int vt_batch_stride, int d, float scale,
+                              void* stream);
+
 /* GEGLU: y[r][0:c] = a[r][0:c] * gelu_erf(a[r][c:2c]) */
 int sdeo_geglu_f16(void* y, const void* a, int rows, int c, void* stream);
 
@@ -175,6 +181,30 @@ int sdeo_vae_decode(sdeo_handle h, const float* z, int n, float* images, uint8_t
 
 /* bytes of device memory the handle owns (weights + arena) */
 size_t sdeo_device_bytes(sdeo_handle h);
+
+/* ------------------------------------------------------------------ text encoder
+ * FrozenCLIPEmbedder.forward (ldm/modules/encoders/modules.py:123-141): token ids -> CLIPTextModel ->
+ * last_hidden_state [batch][positions][width].  The tokenizer stays on the host (it needs the vocabulary
+ * files the caller supplies by path).  Tensor names are those of the HuggingFace state dict below
+ * "text_model." ("cond_stage_model.transformer.text_model.*" in an SD checkpoint: anything up to and including
+ * "text_model." is stripped).  openai/clip-vit-large-patch14: vocab 49408, positions 77, width 768, 12 layers,
+ * 12 heads, ffn 3072. */
+typedef struct sdeo_clip_handle_s* sdeo_clip_handle;
+typedef struct sdeo_clip_config {
+  int vocab, positions, width, layers, heads, ffn;
+} sdeo_clip_config;
+int sdeo_clip_create(const sdeo_clip_config* cfg, sdeo_clip_handle* out);
+int sdeo_clip_destroy(sdeo_clip_handle h);
+int sdeo_clip_load_weight(sdeo_clip_handle h, const char* name, const float* host_data, const int64_t* dims, int ndim, int strict);
+int sdeo_clip_finalize_weights(sdeo_clip_handle h);
+int sdeo_clip_num_weights(sdeo_clip_handle h);
+int sdeo_clip_weight_info(sdeo_clip_handle h, int i, const char** name, int64_t dims[2], int* ndim);
+/* fix the number of prompts per call and allocate the activation buffers */
+int sdeo_clip_configure(sdeo_clip_handle h, int batch);
+/* tokens int32 [batch][positions] (device) -> out fp32 [batch][positions][width] (device); ids outside the
+ * vocabulary are clamped */
+int sdeo_clip_encode(sdeo_clip_handle h, const int32_t* tokens, int batch, float* out, void* stream);
+size_t sdeo_clip_device_bytes(sdeo_clip_handle h);
 
 /* Per-kernel timing for bench.py's roofline: between begin and end every launch of the net-level calls is
  * bracketed by HIP events on the stream it runs on; end synchronises the device and returns a JSON array

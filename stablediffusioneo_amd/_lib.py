@@ -31,6 +31,11 @@ class SdeoConfig(C.Structure):
     ]
 
 
+class SdeoClipConfig(C.Structure):
+    _fields_ = [("vocab", C.c_int), ("positions", C.c_int), ("width", C.c_int), ("layers", C.c_int), ("heads", C.c_int),
+                ("ffn", C.c_int)]
+
+
 def declared_symbols(header: str = HEADER):
     """Names of every function include/sdeo.h declares (used by the CPU export test)."""
     txt = open(header).read()
@@ -55,9 +60,10 @@ def load(path: str = LIB_PATH):
         raise SdeoError(f"libsdeo.so does not export {missing}")
     lib.sdeo_last_error.restype = C.c_char_p
     for name in ("sdeo_groupnorm_workspace_bytes", "sdeo_conv2d_workspace_bytes", "sdeo_gemm_workspace_bytes",
-                 "sdeo_device_bytes"):
+                 "sdeo_device_bytes", "sdeo_clip_device_bytes"):
         getattr(lib, name).restype = C.c_size_t
     lib.sdeo_device_bytes.argtypes = [C.c_void_p]
+    lib.sdeo_clip_device_bytes.argtypes = [C.c_void_p]
     lib.sdeo_tuned_gemm_plans_json.restype = C.c_char_p
     _lib = lib
     load_tuned_plans(lib)

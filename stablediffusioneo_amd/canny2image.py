@@ -80,11 +80,22 @@ def _default_canny():
 class hackathon():
 
     def initialize(self, weights="synthetic:0", config="sd15", apply_canny=None, text_encoder=None):
+        """text_encoder: None = `synthetic_text_encoder` (seeded stand-in contexts); "clip" or "clip:<tokenizer dir>" = the
+        FrozenCLIPEmbedder mirror on the HIP path (weights from the same source as the UNet's: synthetic seed or the
+        checkpoint's `cond_stage_model.transformer.text_model.*`); or any callable(prompts) -> (B, 77, 768) tensor."""
         self.apply_canny = apply_canny or _default_canny()
+        if isinstance(text_encoder, str) and text_encoder.split(":")[0] == "clip":
+            from . import spec as S
+            from .ldm.modules.encoders.modules import FrozenCLIPEmbedder
+            tok_dir = text_encoder.split(":", 1)[1] if ":" in text_encoder else None
+            text_encoder = FrozenCLIPEmbedder(version=tok_dir, config=S.CLIP_TINY if config == "tiny" else S.CLIP_SD15)
         self.text_encoder = text_encoder or synthetic_text_encoder
         self.model = create_model(config, cond_stage_model=self.text_encoder)
         if isinstance(weights, str) and weights.startswith("synthetic"):
-            self.model.rt.load_synthetic(int(weights.split(":")[1]) if ":" in weights else 0)
+            seed = int(weights.split(":")[1]) if ":" in weights else 0
+            self.model.rt.load_synthetic(seed)
+            if hasattr(self.text_encoder, "transformer"):
+                self.text_encoder.transformer.load_synthetic(seed)
         elif isinstance(weights, dict):
             self.model.load_state_dict(weights)
         else:

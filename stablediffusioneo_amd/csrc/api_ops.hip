@@ -115,6 +115,12 @@ int sdeo_attention_f16(void* o, int ldo, const void* q, int ldq, const void* k, 
                    vt_batch_stride, d, scale, S(stream));
 }
 
+int sdeo_attention_causal_f16(void* o, int ldo, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int b,
+                              int heads, int tq, int tk, int tk_stride, int vt_batch_stride, int d, float scale, void* stream) {
+  return attention((f16*)o, ldo, (const f16*)q, ldq, (const f16*)k, ldk, (const f16*)vt, ldvt, b, heads, tq, tk, tk_stride,
+                   vt_batch_stride, d, scale, S(stream), 1);
+}
+
 int sdeo_geglu_f16(void* y, const void* a, int rows, int c, void* stream) {
   return geglu((f16*)y, c, (const f16*)a, 2 * c, rows, c, S(stream));
 }

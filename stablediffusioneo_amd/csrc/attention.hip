@@ -31,6 +31,7 @@ struct AP {
   int ldo, ldq, ldk, ldvt;
   int H, Tq, Tk, TkS, TkSv, d;
   float scale_log2;
+  int causal;        // 1: key j is visible to query t only when j <= t (CLIP text transformer)
 };
 
 // KS = 1: four waves, each owning 32 queries and walking all keys.  KS = 2 ("key split"): eight waves, the two waves of a
@@ -186,7 +187,7 @@ void attention_kernel(const AP p) {
     }
     // ---- online softmax (base-2), key index of s[kb][r] = kt*64 + kb*32 + (r&3) + 8*(r>>2) + 4*lh
     //      the running max is kept in scaled units (score * scale * log2 e); the scale itself is folded into one fma
-    const bool tail = (kt + 1) * 64 > p.Tk;
+    const bool tail = (kt + 1) * 64 > p.Tk || p.causal;
     float mx = -INFINITY;
 #pragma unroll
     for (int ki = 0; ki < NKB; ++ki)
@@ -195,7 +196,7 @@ void attention_kernel(const AP p) {
         if (tail) {
           const int kb = KS == 2 ? kh : ki;
           const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (key >= p.Tk) s[ki][r] = -INFINITY;
+          if (key >= p.Tk || (p.causal && key > qrow)) s[ki][r] = -INFINITY;
         }
         mx = fmaxf(mx, s[ki][r]);
       }
@@ -329,14 +330,15 @@ static int launch_attn(const AP& ap, int B, hipStream_t stream) {
 }
 
 int attention(f16* o, int ldo, const f16* q, int ldq, const f16* k, int ldk, const f16* vt, int ldvt, int B, int H,
-              int Tq, int Tk, int TkS, int TkSv, int d, float scale, hipStream_t stream) {
+              int Tq, int Tk, int TkS, int TkSv, int d, float scale, hipStream_t stream, int causal) {
   SDEO_CHECK(o && q && k && vt, "attention: null operand");
   SDEO_CHECK(B > 0 && H > 0 && Tq > 0 && Tk > 0 && TkS >= Tk && TkSv >= Tk, "attention: bad sizes B=%d H=%d Tq=%d Tk=%d TkS=%d TkSv=%d", B,
              H, Tq, Tk, TkS, TkSv);
   SDEO_CHECK(d % 8 == 0 && d >= 8 && d <= 160, "attention: head dim %d unsupported (multiple of 8, <= 160)", d);
   SDEO_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && TkSv % 8 == 0,
              "attention: strides must keep 16-byte alignment (ldq=%d ldk=%d ldvt=%d ldo=%d TkSv=%d)", ldq, ldk, ldvt, ldo, TkSv);
-  AP ap{o, q, k, vt, ldo, ldq, ldk, ldvt, H, Tq, Tk, TkS, TkSv, d, scale * 1.4426950408889634f};
+  SDEO_CHECK(!causal || Tq == Tk, "attention: causal needs Tq == Tk (got %d, %d)", Tq, Tk);
+  AP ap{o, q, k, vt, ldo, ldq, ldk, ldvt, H, Tq, Tk, TkS, TkSv, d, scale * 1.4426950408889634f, causal ? 1 : 0};
   const int d16 = cdiv(d, 16);
   switch (d16) {
     case 1: return launch_attn<1>(ap, B, stream);

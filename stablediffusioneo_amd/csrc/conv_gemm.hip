@@ -93,6 +93,9 @@ __device__ __forceinline__ void epilogue(const KP& p, f32x4 (&acc)[NI][MI], int 
       if (p.act == 1) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = quick_gelu_f(v[t]);
       }
       v *= p.scale;
       if (p.res) {
@@ -622,6 +625,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KP p) {
   if (p.act == 1) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
+  } else if (p.act == 2) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = quick_gelu_f(v[t]);
   }
   v *= p.scale;
 #pragma unroll

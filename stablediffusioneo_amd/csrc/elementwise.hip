@@ -271,4 +271,46 @@ int cfg_ddim_step(float* x_prev, float* pred_x0, const float* x, const float* ep
   return 0;
 }
 
+__global__ __launch_bounds__(256) void f16_to_f32_kernel(float* __restrict__ y, const f16* __restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = (float)x[i];
+}
+
+int f16_to_f32(float* y, const f16* x, int64_t n, hipStream_t stream) {
+  SDEO_CHECK(y && x && n > 0, "f16_to_f32: bad operand");
+  hipLaunchKernelGGL(f16_to_f32_kernel, grid_for(n), dim3(256), 0, stream, y, x, n);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+// one thread per 8 channels of one token
+__global__ __launch_bounds__(256) void embed_tokens_kernel(f16* __restrict__ out, const int32_t* __restrict__ ids,
+                                                           const f16* __restrict__ tok_emb, const f16* __restrict__ pos_emb, int B,
+                                                           int T, int W, int vocab) {
+  const int w8 = W / 8;
+  const int64_t total = (int64_t)B * T * w8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % w8) * 8;
+    const int64_t row = i / w8;
+    const int t = (int)(row % T);
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const f16x8 a = *reinterpret_cast<const f16x8*>(tok_emb + (size_t)id * W + c);
+    const f16x8 b = *reinterpret_cast<const f16x8*>(pos_emb + (size_t)t * W + c);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (f16)((float)a[j] + (float)b[j]);
+    *reinterpret_cast<f16x8*>(out + (size_t)row * W + c) = o;
+  }
+}
+
+int embed_tokens(f16* out, const int32_t* ids, const f16* tok_emb, const f16* pos_emb, int B, int T, int W, int vocab,
+                 hipStream_t stream) {
+  SDEO_CHECK(out && ids && tok_emb && pos_emb, "embed_tokens: null operand");
+  SDEO_CHECK(B > 0 && T > 0 && W > 0 && W % 8 == 0 && vocab > 0, "embed_tokens: bad sizes B=%d T=%d W=%d vocab=%d", B, T, W, vocab);
+  hipLaunchKernelGGL(embed_tokens_kernel, grid_for((int64_t)B * T * (W / 8)), dim3(256), 0, stream, out, ids, tok_emb, pos_emb, B, T, W,
+                     vocab);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace sdeo

@@ -27,7 +27,7 @@ struct ConvGemm {
   int Ho = 1, Wo = 1, R = 1, S = 1, stride = 1, pad = 0;
   int ups = 0;                 // 1: the conv sees the source nearest-upsampled x2 (Upsample folded in)
   int ldx = 0, ldw = 0, ldy = 0, ldres = 0, ld_bias2 = 0;
-  int act = 0;                 // 0 none, 1 SiLU
+  int act = 0;                 // 0 none, 1 SiLU, 2 quick-GELU  v * sigmoid(1.702 v)  (CLIP MLP)
   int bias_per_row = 0;
   float scale = 1.0f;
   int force_tile = -1;         // testing hook: tile config index
@@ -61,9 +61,10 @@ int layernorm(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const 
 // Fused attention  O = softmax(Q K^T * scale) V   (flash-style, scores never materialised)
 //   Q[(b*Tq+t)*ldq + h*d + i], K[(b*TkS+j)*ldk + h*d + i], Vt[(h*d+i)*ldvt + b*TkSv + j]
 //   O[(b*Tq+t)*ldo + h*d + i];  keys j >= Tk are masked;  TkS / TkSv = per-batch strides of K rows / V^T columns.
+//   causal: key j additionally masked for query t when j > t (needs Tq == Tk).
 // ------------------------------------------------------------------------------------------
 int attention(f16* o, int ldo, const f16* q, int ldq, const f16* k, int ldk, const f16* vt, int ldvt, int B, int H,
-              int Tq, int Tk, int TkS, int TkSv, int d, float scale, hipStream_t stream);
+              int Tq, int Tk, int TkS, int TkSv, int d, float scale, hipStream_t stream, int causal = 0);
 // vt[c][b*TkSv + t] = v[(b*T + t)*ldv + c]   (fallback when T is too small for the transposed GEMM)
 int transpose_pad(f16* vt, int ldvt, const f16* v, int ldv, int B, int T, int TkSv, int C, hipStream_t stream);
 
@@ -91,6 +92,10 @@ int nhwc_f16_to_nhwc_u8(uint8_t* y, const f16* x, int ldx, int64_t pixels, int C
 int oihw_f32_to_ohwi_f16(f16* y, const float* w, int O, int I, int R, int S, int Ipad, hipStream_t stream);
 int zero_f16(f16* y, int64_t n, hipStream_t stream);
 int f32_to_f16(f16* y, const float* x, int64_t n, hipStream_t stream);
+int f16_to_f32(float* y, const f16* x, int64_t n, hipStream_t stream);
+// CLIP text embeddings: out[(b*T + t)][0:W] = tok_emb[ids[b*T + t]][0:W] + pos_emb[t][0:W]   (ids are clamped to [0, vocab))
+int embed_tokens(f16* out, const int32_t* ids, const f16* tok_emb, const f16* pos_emb, int B, int T, int W, int vocab,
+                 hipStream_t stream);
 // classifier-free guidance + DDIM update on NCHW fp32 latents (ddim_hacked.py:192,208-231)
 int cfg_ddim_step(float* x_prev, float* pred_x0, const float* x, const float* eps_c, const float* eps_u, const float* noise,
                   float cfg_scale, float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at, int64_t n,

@@ -94,8 +94,8 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return y
 
 
-def attention(q, k, vt, heads, tk=None, scale=None):
-    """q (B,Tq,H*d), k (B,TkS,H*d), vt (H*d, B*TkS) fp16 -> (B,Tq,H*d)."""
+def attention(q, k, vt, heads, tk=None, scale=None, causal=False):
+    """q (B,Tq,H*d), k (B,TkS,H*d), vt (H*d, B*TkS) fp16 -> (B,Tq,H*d); causal masks key j > query t (Tq == tk)."""
     lib = _lib.load()
     _need_cuda(q, k, vt)
     b, tq, c = q.shape
@@ -105,8 +105,9 @@ def attention(q, k, vt, heads, tk=None, scale=None):
     scale = d ** -0.5 if scale is None else scale
     assert q.is_contiguous() and k.is_contiguous() and vt.is_contiguous() and vt.shape == (c, b * tks)
     o = torch.empty_like(q)
-    check(lib.sdeo_attention_f16(ptr(o), _i(c), ptr(q), _i(c), ptr(k), _i(k.shape[2]), ptr(vt), _i(b * tks), _i(b), _i(heads),
-                                 _i(tq), _i(tk), _i(tks), _i(tks), _i(d), _f(scale), cur_stream()), "attention")
+    fn = lib.sdeo_attention_causal_f16 if causal else lib.sdeo_attention_f16
+    check(fn(ptr(o), _i(c), ptr(q), _i(c), ptr(k), _i(k.shape[2]), ptr(vt), _i(b * tks), _i(b), _i(heads),
+             _i(tq), _i(tk), _i(tks), _i(tks), _i(d), _f(scale), cur_stream()), "attention")
     return o
 
 

@@ -234,3 +234,80 @@ class SdeoRuntime:
         u8 = torch.empty((b, 8 * self.h, 8 * self.w, v.out_ch), dtype=torch.uint8, device=self.device) if want_u8 else None
         check(self.lib.sdeo_vae_decode(self.handle, ptr(z), C.c_int(b), ptr(img), ptr(u8), cur_stream()), "vae_decode")
         return (img, u8) if want_u8 else img
+
+
+class ClipRuntime:
+    """CLIP text transformer on the HIP path: create -> load_state_dict -> configure(batch) ->
+    encode(tokens).  Mirrors what `FrozenCLIPEmbedder.forward` does after tokenisation
+    (`ldm/modules/encoders/modules.py:126-131`: `self.transformer(input_ids=tokens).last_hidden_state`)."""
+
+    def __init__(self, cfg: S.ClipConfig = S.CLIP_SD15, device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise _lib.SdeoError("ClipRuntime needs a HIP device (there is no CPU fallback)")
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        torch.cuda.set_device(self.device)
+        self.handle = C.c_void_p()
+        self._cfg = _lib.SdeoClipConfig(cfg.vocab, cfg.positions, cfg.width, cfg.layers, cfg.heads, cfg.ffn)
+        check(self.lib.sdeo_clip_create(C.byref(self._cfg), C.byref(self.handle)), "sdeo_clip_create")
+        self.batch = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and self.handle.value:
+                self.lib.sdeo_clip_destroy(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:
+            pass
+
+    def expected_weights(self) -> Dict[str, tuple]:
+        out = {}
+        name = C.c_char_p()
+        dims = (C.c_int64 * 2)()
+        nd = C.c_int()
+        for i in range(self.lib.sdeo_clip_num_weights(self.handle)):
+            check(self.lib.sdeo_clip_weight_info(self.handle, C.c_int(i), C.byref(name), dims, C.byref(nd)), "clip_weight_info")
+            out[name.value.decode()] = tuple(int(dims[k]) for k in range(nd.value))
+        return out
+
+    def load_tensor(self, name: str, t: torch.Tensor, strict: bool = True):
+        t = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+        dims = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+        check(self.lib.sdeo_clip_load_weight(self.handle, name.encode(), C.c_void_p(t.data_ptr()), dims, C.c_int(t.dim()),
+                                             C.c_int(int(strict))), f"clip_load_weight({name})")
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
+        """Accepts HuggingFace names (`text_model.*`, or bare), or the SD checkpoint's `cond_stage_model.transformer.text_model.*`;
+        anything else (e.g. `position_ids`, the UNet tensors of a full checkpoint) is ignored unless strict."""
+        for k, v in sd.items():
+            if not torch.is_floating_point(v):
+                continue
+            self.load_tensor(k, v, strict)
+        check(self.lib.sdeo_clip_finalize_weights(self.handle), "clip_finalize_weights")
+        return self
+
+    def load_synthetic(self, seed: int = 0):
+        for name, shape in self.expected_weights().items():
+            self.load_tensor(name, S.synth_tensor(S.NS_CLIP + name, shape, seed))
+        check(self.lib.sdeo_clip_finalize_weights(self.handle), "clip_finalize_weights")
+        return self
+
+    def configure(self, batch: int):
+        check(self.lib.sdeo_clip_configure(self.handle, C.c_int(batch)), "sdeo_clip_configure")
+        self.batch = batch
+        return self
+
+    def encode(self, tokens: torch.Tensor) -> torch.Tensor:
+        """tokens: integer [batch, positions] -> fp32 [batch, positions, width] on the device."""
+        if tokens.dim() != 2 or tokens.shape[1] != self.cfg.positions:
+            raise ValueError(f"tokens must be [batch, {self.cfg.positions}], got {tuple(tokens.shape)}")
+        if tokens.shape[0] != self.batch:
+            self.configure(int(tokens.shape[0]))
+        tok = tokens.to(device=self.device, dtype=torch.int32).contiguous()
+        out = torch.empty((self.batch, self.cfg.positions, self.cfg.width), dtype=torch.float32, device=self.device)
+        check(self.lib.sdeo_clip_encode(self.handle, ptr(tok), C.c_int(self.batch), ptr(out), cur_stream()), "sdeo_clip_encode")
+        return out
+
+    def device_bytes(self) -> int:
+        return int(self.lib.sdeo_clip_device_bytes(self.handle))

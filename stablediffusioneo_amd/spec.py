@@ -347,6 +347,47 @@ def _seed_for(seed: int, name: str) -> int:
     return int.from_bytes(h[:7], "little")
 
 
+@dataclass(frozen=True)
+class ClipConfig:
+    """CLIP text transformer behind `FrozenCLIPEmbedder` (`ldm/modules/encoders/modules.py:90-141`):
+    openai/clip-vit-large-patch14 text tower (HuggingFace `CLIPTextConfig` of that checkpoint)."""
+    vocab: int = 49408
+    positions: int = 77
+    width: int = 768
+    layers: int = 12
+    heads: int = 12
+    ffn: int = 3072
+
+
+CLIP_SD15 = ClipConfig()
+CLIP_TINY = ClipConfig(vocab=1000, positions=77, width=64, layers=2, heads=4, ffn=128)
+NS_CLIP = "cond_stage_model.transformer.text_model."
+
+
+def param_spec_clip(cfg: ClipConfig = CLIP_SD15) -> "OrderedDict[str, tuple]":
+    """Tensor names below `text_model.` and shapes of the HuggingFace CLIPTextModel state dict."""
+    w, f = cfg.width, cfg.ffn
+    spec = OrderedDict()
+    spec["embeddings.token_embedding.weight"] = (cfg.vocab, w)
+    spec["embeddings.position_embedding.weight"] = (cfg.positions, w)
+    for i in range(cfg.layers):
+        p = f"encoder.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            spec[p + f"self_attn.{n}.weight"] = (w, w)
+            spec[p + f"self_attn.{n}.bias"] = (w,)
+        spec[p + "layer_norm1.weight"] = (w,)
+        spec[p + "layer_norm1.bias"] = (w,)
+        spec[p + "mlp.fc1.weight"] = (f, w)
+        spec[p + "mlp.fc1.bias"] = (f,)
+        spec[p + "mlp.fc2.weight"] = (w, f)
+        spec[p + "mlp.fc2.bias"] = (w,)
+        spec[p + "layer_norm2.weight"] = (w,)
+        spec[p + "layer_norm2.bias"] = (w,)
+    spec["final_layer_norm.weight"] = (w,)
+    spec["final_layer_norm.bias"] = (w,)
+    return spec
+
+
 def synth_tensor(name: str, shape, seed: int = 0) -> torch.Tensor:
     """Deterministic stand-in for one checkpoint tensor (fp32, CPU).
 
@@ -358,10 +399,12 @@ def synth_tensor(name: str, shape, seed: int = 0) -> torch.Tensor:
     shape = tuple(shape)
     leaf = name.rsplit(".", 1)[-1]
     if len(shape) == 1:
-        is_norm = any(t in name for t in (".norm", "in_layers.0", "out_layers.0", "out.0", "norm_out"))
+        is_norm = any(t in name for t in (".norm", "in_layers.0", "out_layers.0", "out.0", "norm_out", "layer_norm"))
         if leaf == "weight" and is_norm:
             return 1.0 + 0.1 * torch.randn(shape, generator=g)
         return 0.02 * torch.randn(shape, generator=g)
+    if "_embedding.weight" in name:          # CLIP token / position tables: entries of order 0.02-ish like the real ones
+        return 0.05 * torch.randn(shape, generator=g)
     fan_in = 1
     for d in shape[1:]:
         fan_in *= d

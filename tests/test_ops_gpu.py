@@ -264,6 +264,26 @@ def test_attention(ops, case):
     assert_close(o, ref, rtol=3e-3, atol=3e-3, what=f"attention {case}")
 
 
+@pytest.mark.parametrize("case", [(2, 12, 77, 64), (1, 4, 16, 16), (2, 8, 320, 40), (1, 2, 130, 80)])
+def test_attention_causal(ops, case):
+    """CLIP text transformer mask: key j is visible to query t only when j <= t"""
+    b, hds, t, d = case
+    c = hds * d
+    ts = ((t + 7) // 8) * 8
+    q = h16(randn((b, t, c), 520 + d))
+    k = torch.zeros((b, ts, c), dtype=torch.float16)
+    v = torch.zeros((b, ts, c), dtype=torch.float16)
+    k[:, :t] = h16(randn((b, t, c), 521))
+    v[:, :t] = h16(randn((b, t, c), 522))
+    sp = lambda x: x.float().reshape(b, t, hds, d).permute(0, 2, 1, 3)
+    sim = torch.einsum("bhid,bhjd->bhij", sp(q), sp(k[:, :t])) * d ** -0.5
+    sim = sim + torch.full((t, t), float("-inf")).triu(1)
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(v[:, :t])).permute(0, 2, 1, 3).reshape(b, t, c)
+    vt = v.reshape(b * ts, c).t().contiguous()
+    o = ops.attention(q.to(DEV), k.to(DEV), vt.to(DEV), hds, tk=t, causal=True)
+    assert_close(o, ref, rtol=3e-3, atol=3e-3, what=f"causal attention {case}")
+
+
 def test_attention_spike(ops):
     """force the online-softmax rescale: one key dominates late in the sequence"""
     b, hds, t, d = 1, 4, 256, 32

@@ -187,3 +187,29 @@ def test_hackathon_process(tiny_model):
     assert len(out) == 2 and out[0].shape == (64, 128, 3) and out[0].dtype == np.uint8
     out2 = hk.process(img, "a bird", "best quality", "lowres", 2, 64, 4, False, 1.0, 9.0, 2946901, 0.0, 100, 200)
     assert np.array_equal(out[0], out2[0])       # same seed -> same image
+
+
+def test_hackathon_process_with_clip_text_encoder(tiny_model):
+    """process() with the FrozenCLIPEmbedder mirror as cond_stage_model (tokenise -> sdeo_clip_encode -> contexts)"""
+    from stablediffusioneo_amd import canny2image as c2i, spec as S
+    from stablediffusioneo_amd.cldm.ddim_hacked import DDIMSampler
+    from stablediffusioneo_amd.ldm.modules.encoders.modules import FrozenCLIPEmbedder
+    from stablediffusioneo_amd.runtime import ClipRuntime
+    ccfg = S.ClipConfig(vocab=1000, positions=77, width=tiny_model.rt.ucfg.context_dim, layers=2, heads=4, ffn=192)
+    enc = FrozenCLIPEmbedder(config=ccfg, runtime=ClipRuntime(ccfg).load_synthetic(5))
+    hk = c2i.hackathon()
+    hk.apply_canny = lambda img, lo, hi: ((np.random.RandomState(3).rand(*img.shape[:2]) < 0.08) * 255).astype(np.uint8)
+    hk.text_encoder = enc
+    old = tiny_model.cond_stage_model
+    tiny_model.cond_stage_model = enc
+    try:
+        hk.model = tiny_model
+        hk.ddim_sampler = DDIMSampler(tiny_model)
+        img = (np.random.RandomState(0).rand(96, 144, 3) * 255).astype(np.uint8)
+        a = hk.process(img, "a bird", "best quality", "lowres", 1, 64, 4, False, 1.0, 9.0, 2946901, 0.0, 100, 200)
+        b = hk.process(img, "a bird", "best quality", "lowres", 1, 64, 4, False, 1.0, 9.0, 2946901, 0.0, 100, 200)
+        c = hk.process(img, "a fish", "best quality", "lowres", 1, 64, 4, False, 1.0, 9.0, 2946901, 0.0, 100, 200)
+        assert a[0].shape == (64, 128, 3) and np.array_equal(a[0], b[0])
+        assert not np.array_equal(a[0], c[0])        # the prompt reaches the image through the text encoder
+    finally:
+        tiny_model.cond_stage_model = old
