@@ -172,12 +172,13 @@ class DDIMSampler(object):
             # e.g. guess mode: the unconditional branch runs without ControlNet (`canny2image_torch.py:48`)
             return m.apply_model(x, t, c), m.apply_model(x, t, uc)
         b = x.shape[0]
-        hint_c, hint_u = torch.cat(c["c_concat"], 1), torch.cat(uc["c_concat"], 1)
-        ctx_c, ctx_u = torch.cat(c["c_crossattn"], 1), torch.cat(uc["c_crossattn"], 1)
-        key = (hint_c.data_ptr(), hint_u.data_ptr(), ctx_c.data_ptr(), ctx_u.data_ptr(), hint_c._version, ctx_c._version,
-               ctx_u._version, tuple(x.shape))
-        flags = 0
-        pair = {"c_concat": None, "c_crossattn": None}
+
+        # identity of the CALLER's conditioning tensors (storage, in-place version, shape): a key built from the result of
+        # torch.cat would compare addresses of temporaries, which match from step to step only by allocator luck
+        def ident(ts):
+            return tuple((v.data_ptr(), v._version, tuple(v.shape)) for v in ts)
+
+        key = (ident(c["c_concat"]), ident(uc["c_concat"]), ident(c["c_crossattn"]), ident(uc["c_crossattn"]), tuple(x.shape))
         if key == self._cache_key:
             rt = m.rt.configure(2 * b, x.shape[2], x.shape[3])
             if USE_GRAPH:
@@ -186,6 +187,8 @@ class DDIMSampler(object):
                 eps2 = rt.apply_model(torch.cat([x, x]), None, torch.cat([t, t]), None, m.control_scales,
                                       m.only_mid_control, HINT_CACHED | CONTEXT_CACHED)
         else:
+            hint_c, hint_u = torch.cat(c["c_concat"], 1), torch.cat(uc["c_concat"], 1)
+            ctx_c, ctx_u = torch.cat(c["c_crossattn"], 1), torch.cat(uc["c_crossattn"], 1)
             pair = {"c_concat": [torch.cat([hint_c, hint_u])], "c_crossattn": [torch.cat([ctx_c, ctx_u])]}
             eps2 = m.apply_model(torch.cat([x, x]), torch.cat([t, t]), pair)
             self._cache_key = key

@@ -185,6 +185,7 @@ struct T {           // fp16 activation view: rows x c, row stride ld; (n,h,w) w
 struct Op {          // one launch of a program + what it is for the profiler
   std::function<int(hipStream_t)> fn;
   const char* key = "other";
+  std::string tag;           // problem shape, shown by the profiler when SDEO_PROFILE_DETAIL=1
   double flops = 0, bytes = 0;
   template <class F>
   Op(F f) : fn(std::move(f)) {}
@@ -192,7 +193,7 @@ struct Op {          // one launch of a program + what it is for the profiler
 };
 typedef std::vector<Op> Program;
 
-struct ProfRec { const char* key; double flops, bytes; hipEvent_t a, b; };
+struct ProfRec { std::string key; double flops, bytes; hipEvent_t a, b; };
 
 }  // namespace
 
@@ -459,8 +460,8 @@ struct Builder {
     if (t.off != (size_t)-1) arena->release(t.off);
     t.off = (size_t)-1;
   }
-  void push(Op op, const char* key = "elementwise", double flops = 0, double bytes = 0) {
-    op.key = key; op.flops = flops; op.bytes = bytes;
+  void push(Op op, const char* key = "elementwise", double flops = 0, double bytes = 0, const std::string& tag = std::string()) {
+    op.key = key; op.flops = flops; op.bytes = bytes; op.tag = tag;
     if (!dry) prog->push_back(std::move(op));
   }
 
@@ -494,7 +495,9 @@ struct Builder {
       if (scale_host) p.scale = *scale_host;
       return conv_gemm(p, s);
     }, conv_gemm_kernel_name(p), 2.0 * p.M * p.N * p.K,
-       2.0 * ((double)p.M * p.Cin * (p.R * p.S > 1 ? 1 : 1) + (double)p.N * p.K + (double)p.M * p.N));
+       2.0 * ((double)p.M * p.Cin * (p.R * p.S > 1 ? 1 : 1) + (double)p.N * p.K + (double)p.M * p.N),
+       "M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) + " R" + std::to_string(p.R) + " s" +
+           std::to_string(p.stride) + " u" + std::to_string(p.ups));
   }
 
   // conv on an image view; weights by name (".weight"/".bias" appended)
@@ -557,7 +560,7 @@ struct Builder {
     const int sel = ws_sel;
     const f16* xp = x.p; f16* yp = y.p; const int ldx = x.ld, ldy = y.ld;
     push([=](hipStream_t s) { return groupnorm_nhwc(yp, ldy, xp, ldx, g, b, B, HW, C, 32, eps, silu_, sel ? eng->gn_ws2 : eng->gn_ws, s); }, "groupnorm", 0,
-         3.0 * 2.0 * B * HW * C);
+         3.0 * 2.0 * B * HW * C, "C" + std::to_string(C) + " HW" + std::to_string(HW));
     if (out) y.off = (size_t)-1;
     return y;
   }
@@ -567,7 +570,8 @@ struct Builder {
     const float* g = vptr(name + ".weight");
     const float* b = vptr(name + ".bias");
     const f16* xp = x.p; f16* yp = y.p; const int ldx = x.ld, ldy = y.ld, rows = x.rows(), C = x.c;
-    push([=](hipStream_t s) { return layernorm(yp, ldy, xp, ldx, g, b, rows, C, 1e-5f, s); }, "layernorm", 0, 4.0 * rows * C);
+    push([=](hipStream_t s) { return layernorm(yp, ldy, xp, ldx, g, b, rows, C, 1e-5f, s); }, "layernorm", 0, 4.0 * rows * C,
+         "rows" + std::to_string(rows) + " C" + std::to_string(C));
     return y;
   }
 
@@ -575,7 +579,8 @@ struct Builder {
     f16* op = o.p; const int ldo = o.ld;
     const float scale = 1.0f / sqrtf((float)d);
     push([=](hipStream_t s) { return attention(op, ldo, q, ldq, k, ldk, vt, ldvt, B, H, Tq, Tk, TkS, TkSv, d, scale, s); }, "attention",
-         4.0 * B * H * (double)Tq * Tk * d, 2.0 * B * H * d * (2.0 * Tq + 2.0 * Tk));
+         4.0 * B * H * (double)Tq * Tk * d, 2.0 * B * H * d * (2.0 * Tq + 2.0 * Tk),
+         "Tq" + std::to_string(Tq) + " Tk" + std::to_string(Tk) + " d" + std::to_string(d));
   }
 };
 
@@ -723,8 +728,9 @@ static int run(Engine* e, const Program& p, hipStream_t s) {
     }
     return 0;
   }
+  static const bool detail = [] { const char* v = getenv("SDEO_PROFILE_DETAIL"); return v && atoi(v) != 0; }();
   for (auto& op : p) {
-    ProfRec r{op.key, op.flops, op.bytes, nullptr, nullptr};
+    ProfRec r{detail && !op.tag.empty() ? std::string(op.key) + " | " + op.tag : std::string(op.key), op.flops, op.bytes, nullptr, nullptr};
     SDEO_HIP(hipEventCreate(&r.a));
     SDEO_HIP(hipEventCreate(&r.b));
     SDEO_HIP(hipEventRecord(r.a, s));
@@ -1392,7 +1398,7 @@ const char* sdeo_profile_end(sdeo_handle h) {
   }
   h->prof.clear();
   std::string out = "[";
-  char buf[512];
+  char buf[768];
   for (size_t i = 0; i < aggs.size(); ++i) {
     snprintf(buf, sizeof(buf), "%s{\"kernel\": \"%s\", \"launches\": %ld, \"total_ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
              i ? ", " : "", aggs[i].first.c_str(), aggs[i].second.n, aggs[i].second.ms, aggs[i].second.flops, aggs[i].second.bytes);

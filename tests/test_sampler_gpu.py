@@ -141,6 +141,35 @@ def test_fused_cfg_pair_equals_two_passes(tiny_model):
     assert rel(e2[:1], e_c) < 6e-3 and rel(e2[1:], e_u) < 6e-3
 
 
+def test_hint_and_context_are_computed_once_per_image(tiny_model):
+    """The hint block and the cross-attention K/V depend on (hint, context) only (`cldm/cldm.py:288`): after the first
+    DDIM step of an image every further step must take the cached path.  Counted through the in-library profiler:
+    launches(S) must be affine in S with a per-step increment SMALLER than the first (uncached) step."""
+    import stablediffusioneo_amd.cldm.ddim_hacked as dh
+    m = tiny_model
+    m.control_scales = [1.0] * 13
+    dev = m.device
+    x, ctx, hint = make_inputs(1, 8, 8, ctx_dim=m.rt.ucfg.context_dim)
+    ctx_u = randn((1, 77, m.rt.ucfg.context_dim), 2)
+    cond = {"c_concat": [hint.to(dev)], "c_crossattn": [ctx.to(dev)]}
+    unc = {"c_concat": [hint.to(dev)], "c_crossattn": [ctx_u.to(dev)]}
+    s = dh.DDIMSampler(m)
+    saved = dh.USE_GRAPH
+    dh.USE_GRAPH = False
+    try:
+        counts = []
+        for steps in (1, 2, 4):
+            m.rt.profile_begin()
+            s.sample(steps, 1, (4, 8, 8), cond, verbose=False, eta=0.0, unconditional_guidance_scale=9.0,
+                     unconditional_conditioning=unc, x_T=x)
+            counts.append(sum(k["launches"] for k in m.rt.profile_end()))
+    finally:
+        dh.USE_GRAPH = saved
+    first, per_step = counts[0], counts[1] - counts[0]
+    assert per_step < first, counts                      # cached steps skip the hint block and the K/V projections
+    assert counts[2] - counts[1] == 2 * per_step, counts
+
+
 def test_engine_surface(tiny_model):
     """Engine(...).load().activate().allocate_buffers().infer() with the reference's names and positions,
     eager and graph-captured."""
