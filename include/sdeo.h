@@ -51,6 +51,8 @@ void sdeo_debug_force_gemm_order(int order); /* -1 heuristic, 0 M-fastest, 1 N-f
 void sdeo_set_tuned_gemm_plan(const int* key10, int tile, int splitk);
 const char* sdeo_tuned_gemm_plans_json(void);
 /* y = silu(x) on n fp16 elements: launch-floor probe for tools/launch_floor.py */
+/* name of the kernel instantiation sdeo_conv2d_nhwc_f16 would launch for this problem (plan table / forced plan / heuristic) */
+const char* sdeo_debug_conv2d_kernel_name(int n, int h, int w, int cin, int cout, int ksize, int stride, int upsample2x);
 int sdeo_debug_silu(void* y, const void* x, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------ op-level entry points (used by tests)

@@ -70,6 +70,12 @@ size_t sdeo_conv2d_workspace_bytes(int n, int h, int w, int cin, int cout, int k
   return conv_gemm_workspace_bytes(p);
 }
 
+const char* sdeo_debug_conv2d_kernel_name(int n, int h, int w, int cin, int cout, int ksize, int stride, int upsample2x) {
+  ConvGemm p;
+  if (fill_conv(p, n, h, w, cin, cout, ksize, stride, upsample2x)) return "";
+  return conv_gemm_kernel_name(p);
+}
+
 int sdeo_conv2d_nhwc_f16(void* y, const void* x, const void* w_krsc, const float* bias, const float* bias2, const void* res,
                          int n, int h, int w, int cin, int cout, int ksize, int stride, int upsample2x, int act, float scale,
                          void* workspace, size_t workspace_bytes, void* stream) {

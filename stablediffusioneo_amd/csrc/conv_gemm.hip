@@ -29,117 +29,9 @@
 
 #include <utility>
 
-#include "kernels.h"
+#include "conv_inl.h"
 
 namespace sdeo {
-
-struct KP {
-  const f16* x;
-  const f16* w;
-  f16* y;
-  float* y32;
-  const float* bias;
-  const float* bias2;
-  const f16* res;
-  float* ws;
-  int M, N, K;
-  int Hi, Wi, Cin, Ho, Wo, S, stride, pad, ups;
-  int HoWo;
-  int ldx, ldw, ldy, ldres, ld_bias2;
-  int act, bias_per_row;
-  float scale;
-  int nk, nk_per_split, splitk;
-  int tiles_m, tiles_n;
-  // SDEO_DBG_GEMM (measurement only, results are wrong): 1 = activation DMAs read the zero page, 2 = weight DMAs do,
-  // 4 = no MFMAs, 8 = no DMAs after the prologue, 16 = no fragment reads, 32 = no epilogue
-  int dbg;
-  int n_fastest;     // tile order inside an XCD's contiguous run: 1 = all N tiles of an M tile are neighbours
-};
-
-// 256 bytes of zeros: DMA source for padded / out-of-range rows
-__device__ __attribute__((aligned(256))) const unsigned int g_zero_page[64] = {0};
-
-template <int BK>
-__device__ __forceinline__ int swz_chunk(int row, int chunk) {
-  // conflict-free for the 16-lane groups of ds_read_b128 when lanes read rows r..r+15 at one k-chunk
-  if (BK == 64) return chunk ^ ((row >> 1) & 7);
-  return chunk ^ (((row >> 3) & 1) * 3);
-}
-
-// ---- epilogue shared by both kernels: lane holds n = nb + fq*4 + {0..3} (4 consecutive channels) of pixel m
-template <int NI, int MI, int TM, int TN>
-__device__ __forceinline__ void epilogue(const KP& p, f32x4 (&acc)[NI][MI], int m0, int n0, int wm, int wn, int frow, int fq, int z,
-                                         const f32x4 (&bpre)[NI], bool use_bpre) {
-#pragma unroll
-  for (int j = 0; j < MI; ++j) {
-    const int m = m0 + wm * TM + j * 16 + frow;
-    if (m >= p.M) continue;
-    const int b = p.bias2 ? m / p.HoWo : 0;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int n = n0 + wn * TN + i * 16 + fq * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[i][j];
-      if (p.splitk > 1) {
-        *reinterpret_cast<f32x4*>(p.ws + ((size_t)z * p.M + m) * p.N + n) = v;
-        continue;
-      }
-      if (p.bias) {
-        if (p.bias_per_row) v += p.bias[m];
-        else if (use_bpre) v += bpre[i];
-        else v += *reinterpret_cast<const f32x4*>(p.bias + n);
-      }
-      if (p.bias2) v += *reinterpret_cast<const f32x4*>(p.bias2 + (size_t)b * p.ld_bias2 + n);
-      if (p.act == 1) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
-      } else if (p.act == 2) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = quick_gelu_f(v[t]);
-      }
-      v *= p.scale;
-      if (p.res) {
-        const f16x4 r = *reinterpret_cast<const f16x4*>(p.res + (size_t)m * p.ldres + n);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] += (float)r[t];
-      }
-      if (p.y32) {
-        *reinterpret_cast<f32x4*>(p.y32 + (size_t)m * p.ldy + n) = v;
-      } else {
-        f16x4 o;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) o[t] = (f16)v[t];
-        *reinterpret_cast<f16x4*>(p.y + (size_t)m * p.ldy + n) = o;
-      }
-    }
-  }
-}
-
-// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (observed, speed only), so give each
-// XCD a contiguous run of tiles (bijective for any tile count): neighbouring tiles share a weight panel in L2.
-__device__ __forceinline__ int xcd_remap(int wg, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-// compile-time loop (the LDS offsets of the inline-asm fragment reads must be immediates)
-template <int N, typename F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
-}
-template <int OFF>
-__device__ __forceinline__ void lds_read128(f16x8& dst, unsigned addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // ------------------------------------------------------------------------------------------------
 // main kernel: LDS-DMA ring, Cin % 64 == 0
@@ -645,7 +537,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KP p) {
 // ------------------------------------------------------------------------------------------------
 // host side: tile / split-K selection and launch
 // ------------------------------------------------------------------------------------------------
-enum TileKind { TK_DMA, TK_GENERIC };
+enum TileKind { TK_DMA, TK_GENERIC, TK_HALO };
+// TK_HALO (conv_halo.hip): bm = patch pixels, `stages` = index into kHaloCfgs, bk = 64
 struct TileCfg { int bm, bn, bk, stages; TileKind kind; float weight; int wg_per_cu; const char* name; };
 static const TileCfg kTiles[] = {
     {128, 128, 64, 3, TK_DMA, 1.00f, 1, "conv_gemm_dma_kernel<128,128,3>"},
@@ -663,13 +556,32 @@ static const TileCfg kTiles[] = {
     {64, 160, 64, 5, TK_DMA, 0.90f, 1, "conv_gemm_dma_kernel<64,160,5>"},
     {128, 160, 64, 4, TK_DMA, 1.10f, 1, "conv_gemm_dma_kernel<128,160,4>"},
     {128, 64, 64, 5, TK_DMA, 0.85f, 1, "conv_gemm_dma_kernel<128,64,5>"},
+    // halo-reuse 3x3 kernels (stride 1, pad 1, Cin % 64 == 0, image a multiple of the patch)
+    {128, 80, 64, 0, TK_HALO, 1.0f, 1, "conv3x3_halo_kernel<8,16,80>"},
+    {128, 160, 64, 1, TK_HALO, 1.0f, 1, "conv3x3_halo_kernel<8,16,160>"},
+    {64, 80, 64, 2, TK_HALO, 1.0f, 1, "conv3x3_halo_kernel<8,8,80>"},
+    {64, 160, 64, 3, TK_HALO, 1.0f, 1, "conv3x3_halo_kernel<8,8,160>"},
+    {128, 64, 64, 4, TK_HALO, 1.0f, 1, "conv3x3_halo_kernel<8,16,64>"},
+    {128, 128, 64, 5, TK_HALO, 1.0f, 1, "conv3x3_halo_kernel<8,16,128>"},
 };
-static const int kNumTiles = 13;
+static const int kNumTiles = 19;
 static const int kNumCU = 256;
 
 struct Plan { int tile; int splitk; int nk; int tiles_m, tiles_n; };
 
 static bool is_fast(const ConvGemm& p) { return p.Cin % 64 == 0; }
+static bool halo_ok(const ConvGemm& p, const TileCfg& c) {
+  if (c.kind != TK_HALO) return false;
+  const HaloCfg& h = kHaloCfgs[c.stages];
+  return p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && !p.ups && p.Cin % 64 == 0 && p.act != 3 && !p.bias_per_row &&
+         p.Hi % h.ph == 0 && p.Wi % h.pw == 0 && p.Ho == p.Hi && p.Wo == p.Wi;
+}
+// tiles and K-steps of a plan: a halo tile is a patch of one image and steps through Cin in 64-channel slices (9 taps each)
+static int plan_tiles_m(const ConvGemm& p, const TileCfg& c) {
+  if (c.kind == TK_HALO) { const HaloCfg& h = kHaloCfgs[c.stages]; return p.B * (p.Hi / h.ph) * (p.Wi / h.pw); }
+  return cdiv(p.M, c.bm);
+}
+static int plan_nk(const ConvGemm& p, const TileCfg& c) { return c.kind == TK_HALO ? p.Cin / 64 : cdiv(p.K, c.bk); }
 
 // tuning hook (tools/tune_gemm.py): force the tile configuration / split-K factor of every following launch
 static int g_force_tile = -1, g_force_splitk = 0, g_force_order = -1;
@@ -679,41 +591,50 @@ void conv_gemm_debug_force(int tile, int splitk) { g_force_tile = tile; g_force_
 // plans measured on this device by conv_gemm_autotune (shape -> tile, split-K); consulted before the heuristic
 typedef std::array<int, 10> ShapeKey;
 static std::map<ShapeKey, std::pair<int, int>> g_tuned;
-static ShapeKey key_of(const ConvGemm& p) { return {p.M, p.N, p.K, p.Cin, p.R, p.stride, p.ups, p.Hi, p.Wi, p.B}; }
+// (the `ups` slot doubles as the epilogue class: 2 = GEGLU pair epilogue, whose tile menu is restricted)
+static ShapeKey key_of(const ConvGemm& p) { return {p.M, p.N, p.K, p.Cin, p.R, p.stride, p.act == 3 ? 2 : p.ups, p.Hi, p.Wi, p.B}; }
 
 static Plan make_plan(const ConvGemm& p) {
   Plan best{};
   const bool fast = is_fast(p);
   const int force_tile = p.force_tile >= 0 ? p.force_tile : g_force_tile;
   const int force_sk = p.force_splitk > 0 ? p.force_splitk : g_force_splitk;
+  const bool pair = p.act == 3;     // GEGLU epilogue: needs an even number of 16-wide accumulator tiles per wave, no split-K
   if (force_tile < 0 && force_sk <= 0 && fast) {
     auto it = g_tuned.find(key_of(p));
-    if (it != g_tuned.end()) {
+    if (it != g_tuned.end() && !(pair && ((kTiles[it->second.first].bn / 2) % 32 != 0 || it->second.second != 1))) {
       const TileCfg& c = kTiles[it->second.first];
-      const int nk = cdiv(p.K, c.bk);
-      return Plan{it->second.first, it->second.second, nk, cdiv(p.M, c.bm), cdiv(p.N, c.bn)};
+      if (c.kind != TK_HALO || halo_ok(p, c))
+        return Plan{it->second.first, it->second.second, plan_nk(p, c), plan_tiles_m(p, c), cdiv(p.N, c.bn)};
     }
   }
   float best_t = 1e30f;
   for (int t = 0; t < kNumTiles; ++t) {
     const TileCfg& c = kTiles[t];
-    if ((c.kind == TK_DMA) != fast) continue;
-    if (force_tile >= 0 && force_tile != t && (kTiles[force_tile].kind == TK_DMA) == fast) continue;
-    const int tmn = cdiv(p.M, c.bm), tnn = cdiv(p.N, c.bn);
+    auto usable = [&](int ti) {
+      const TileCfg& cc = kTiles[ti];
+      if (cc.kind == TK_HALO) return halo_ok(p, cc);
+      return (cc.kind == TK_DMA) == fast && !(pair && (cc.bn / 2) % 32 != 0);
+    };
+    if (!usable(t)) continue;
+    if (c.kind == TK_HALO && force_tile != t) continue;      // halo tiles enter through the measured plan table or a forced plan only
+    if (force_tile >= 0 && usable(force_tile) && force_tile != t) continue;
+    const int tmn = plan_tiles_m(p, c), tnn = cdiv(p.N, c.bn);
     const int tiles = tmn * tnn;
-    const int nk = cdiv(p.K, c.bk);
+    const int nk = plan_nk(p, c);
+    const bool halo = c.kind == TK_HALO;
     // candidate split-K factors: 1 and whatever gives every CU one or two workgroups
     int cands[3] = {1, 0, 0};
     int ncand = 1;
-    if (tiles < kNumCU && nk >= 8) {
+    if (tiles < kNumCU && (nk >= 8 || halo) && !pair) {
       for (int fill = 1; fill <= 2; ++fill) {
         int sk = fill * kNumCU / tiles;
-        if (sk > nk / 4) sk = nk / 4;
+        if (sk > nk / (halo ? 1 : 4)) sk = nk / (halo ? 1 : 4);
         if (sk > 16) sk = 16;
         if (sk >= 2 && sk != cands[ncand - 1]) cands[ncand++] = sk;
       }
     }
-    if (force_sk > 0) { cands[0] = force_sk > nk ? nk : force_sk; ncand = 1; }
+    if (force_sk > 0 && !pair) { cands[0] = force_sk > nk ? nk : force_sk; ncand = 1; }
     for (int ci = 0; ci < ncand; ++ci) {
       int sk = cands[ci];
       const int per = cdiv(nk, sk);
@@ -722,8 +643,9 @@ static Plan make_plan(const ConvGemm& p) {
       // the source, so a K-step of a workgroup costs max((bm+bn) * 128 B / 28, MFMA time of the tile); the workgroups
       // are spread over 256 CUs; ~9k clocks of launch / prologue / epilogue per kernel
       const float rounds = (float)cdiv(tiles * sk, kNumCU);
-      const float step_clk = fmaxf((float)(c.bm + c.bn) * 4.57f, (float)(c.bm * c.bn) / 31.8f);
-      float tcost = 9000.f + rounds * ((float)per * step_clk + 1500.f);
+      const float step_clk = halo ? fmaxf(((float)c.bm * 0.16f + c.bn) * 4.57f, (float)(c.bm * c.bn) / 31.8f)
+                                  : fmaxf((float)(c.bm + c.bn) * 4.57f, (float)(c.bm * c.bn) / 31.8f);
+      float tcost = 9000.f + rounds * ((float)per * (halo ? 9.f : 1.f) * step_clk + 1500.f);
       if (sk > 1) tcost += 8000.f + ((float)sk + 1.f) * p.M * p.N * 4.0f / 1700.f;   // reduce launch + fp32 slabs at ~4 TB/s
       if (tcost < best_t) { best_t = tcost; best = Plan{t, sk, nk, tmn, tnn}; }
     }
@@ -777,7 +699,7 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
   SDEO_CHECK(p.R >= 1 && p.R <= 4 && p.S >= 1 && p.S <= 4, "conv_gemm: filter %dx%d unsupported (1..4)", p.R, p.S);
   SDEO_CHECK(p.ldw >= p.K, "conv_gemm: ldw=%d < K=%d", p.ldw, p.K);
   SDEO_CHECK(p.M == p.B * p.Ho * p.Wo, "conv_gemm: M=%d != B*Ho*Wo=%d", p.M, p.B * p.Ho * p.Wo);
-  SDEO_CHECK(p.ldy % 4 == 0 && p.ldy >= p.N, "conv_gemm: ldy=%d", p.ldy);
+  SDEO_CHECK(p.ldy % 4 == 0 && p.ldy >= (p.act == 3 ? p.N / 2 : p.N), "conv_gemm: ldy=%d", p.ldy);
   SDEO_CHECK(!p.res || p.ldres % 4 == 0, "conv_gemm: ldres=%d", p.ldres);
   SDEO_CHECK((reinterpret_cast<uintptr_t>(p.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.w) & 15) == 0,
              "conv_gemm: operands must be 16-byte aligned");
@@ -787,7 +709,11 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
                "conv_gemm: geometry mismatch Hi=%d Wi=%d -> Ho=%d Wo=%d (R=%d S=%d stride=%d pad=%d ups=%d)", p.Hi, p.Wi,
                p.Ho, p.Wo, p.R, p.S, p.stride, p.pad, p.ups);
   }
+  if (p.act == 3)
+    SDEO_CHECK(p.N % 32 == 0 && p.y && !p.y32 && !p.res && !p.bias2 && !p.bias_per_row && p.ldy >= p.N / 2 && p.scale == 1.0f,
+               "conv_gemm: GEGLU epilogue needs N %% 32 == 0 (N=%d), fp16 output with ldy >= N/2 and no residual / bias2", p.N);
   const Plan pl = make_plan(p);
+  SDEO_CHECK(p.act != 3 || (pl.splitk == 1 && (kTiles[pl.tile].bn / 2) % 32 == 0), "conv_gemm: no GEGLU-capable plan");
   KP kp{};
   kp.x = p.x; kp.w = p.w; kp.y = p.y; kp.y32 = p.y32; kp.bias = p.bias; kp.bias2 = p.bias2; kp.res = p.res;
   kp.ws = p.workspace;
@@ -829,6 +755,10 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
     case 10: rc = launch_dma<64, 160, 5>(p.ups, kp, tiles, stream); break;
     case 11: rc = launch_dma<128, 160, 4>(p.ups, kp, tiles, stream); break;
     case 12: rc = launch_dma<128, 64, 5>(p.ups, kp, tiles, stream); break;
+    case 13: case 14: case 15: case 16: case 17: case 18:
+      SDEO_CHECK(halo_ok(p, kTiles[pl.tile]), "conv_gemm: halo plan on an ineligible problem");
+      rc = launch_halo(kTiles[pl.tile].stages, kp, pl.tiles_m, pl.tiles_n, stream);
+      break;
     default: return fail("conv_gemm: bad tile %d", pl.tile);
   }
   if (rc) return rc;
@@ -845,7 +775,7 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
 void conv_gemm_set_tuned(const int key[10], int tile, int splitk) {
   ShapeKey k;
   for (int i = 0; i < 10; ++i) k[i] = key[i];
-  if (tile >= 0 && tile < kNumTiles && kTiles[tile].kind == TK_DMA && splitk >= 1) g_tuned[k] = {tile, splitk};
+  if (tile >= 0 && tile < kNumTiles && kTiles[tile].kind != TK_GENERIC && splitk >= 1) g_tuned[k] = {tile, splitk};
 }
 
 std::string conv_gemm_tuned_json() {
@@ -881,18 +811,23 @@ int conv_gemm_autotune(const ConvGemm& p, hipStream_t stream) {
   if (!is_fast(p) || g_force_tile >= 0 || g_force_splitk > 0) return 0;
   const ShapeKey key = key_of(p);
   if (g_tuned.count(key)) return 0;
-  static const int tiles[] = {0, 1, 2, 5, 6, 7, 8, 9};
-  static const int sks[] = {1, 2, 3, 4, 6, 8, 12, 16};
+  static const int tiles[] = {0, 1, 2, 5, 6, 7, 8, 9, 13, 14, 15, 16, 17, 18};
+  static const int sks[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20};
   hipEvent_t a, b;
   SDEO_HIP(hipEventCreate(&a));
   SDEO_HIP(hipEventCreate(&b));
   float best = 1e30f;
   std::pair<int, int> pick(-1, 1);
   for (int t : tiles) {
-    const int nk = cdiv(p.K, kTiles[t].bk);
-    const int wgs1 = cdiv(p.M, kTiles[t].bm) * cdiv(p.N, kTiles[t].bn);
+    const bool halo = kTiles[t].kind == TK_HALO;
+    if (halo && !halo_ok(p, kTiles[t])) continue;
+    const int nk = plan_nk(p, kTiles[t]);
+    const int wgs1 = plan_tiles_m(p, kTiles[t]) * cdiv(p.N, kTiles[t].bn);
+    if (p.act == 3 && (kTiles[t].bn / 2) % 32 != 0) continue;
     for (int sk : sks) {
-      if (sk > 1 && (nk / sk < 4 || (size_t)sk * p.M * p.N * sizeof(float) > p.workspace_bytes || !p.workspace)) continue;
+      if (sk > 1 && p.act == 3) continue;
+      if (sk > 1 && (nk / sk < (halo ? 1 : 4) || (size_t)sk * p.M * p.N * sizeof(float) > p.workspace_bytes || !p.workspace)) continue;
+      if (sk > 1 && make_plan([&] { ConvGemm q = p; q.force_tile = t; q.force_splitk = sk; return q; }()).splitk != sk) continue;   // duplicate of a smaller factor
       if (sk > 1 && wgs1 >= 4 * kNumCU) continue;      // already several rounds of workgroups: splitting K only adds traffic
       ConvGemm q = p;
       q.force_tile = t;

@@ -1,0 +1,260 @@
+// Halo-reuse 3x3 convolution (stride 1, pad 1) for gfx950 on v_mfma_f32_16x16x32_f16.
+//
+// Same arithmetic as the implicit-GEMM kernel of conv_gemm.hip (ResBlock / ResnetBlock 3x3 convs, `openaimodel.py:200-240`,
+// `model.py:129-149`), different data movement.  At batch 1 the 3x3 convs of this model are bound by what a CU can take in
+// through its vector-memory path (~28 B/clk/CU from L2), not by the matrix pipe: an im2col tile brings
+// every activation in nine times (once per filter tap).  Here a workgroup owns a PH x PW patch of output pixels of ONE
+// image and BN output channels, and for each 64-channel slice of Cin stages the (PH+2) x (PW+2) halo patch ONCE; the nine
+// taps are nine K-steps that read their B fragments from the same LDS patch at shifted rows.  Per K-step a CU takes in
+// BN rows of weights + 1/9 of the patch instead of BN + PH*PW rows.
+//
+//  * 8 waves: 0-3 read fragments and issue MFMAs (each owns PH*PW/4 pixels x all BN channels), 4-7 issue LDS-DMAs
+//    (global_load_lds, 16 B per lane, counted s_waitcnt vmcnt + raw s_barrier, weights in a 4-slot ring, patch double-buffered).
+//  * LDS images are the implicit-GEMM kernel's: 128-byte rows (64 channels), 16-byte chunk c of row r stored at chunk
+//    c ^ ((r >> 1) & 7); the permutation is applied to the per-lane SOURCE address and to the fragment reads.
+//  * halo pixels outside the image read a zero page (padding = 1), so every loader lane issues the same number of DMAs.
+//  * split-K over blockIdx.z in units of 64-channel slices; epilogue shared with the implicit-GEMM kernel.
+#include "conv_inl.h"
+
+namespace sdeo {
+
+template <int PH, int PW, int BN>
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const KP p) {
+  constexpr int BM = PH * PW;
+  constexpr int MI = BM / 64, NI = BN / 16;
+  constexpr int HWD = PW + 2, XREAL = (PH + 2) * HWD;
+  constexpr int LXW = (XREAL + 31) / 32;             // patch DMAs per loader wave per Cin slice (8 rows each, 4 loader waves)
+  constexpr int XBYTES = LXW * 32 * 128;
+  constexpr int LW = (BN + 31) / 32;                 // weight DMAs per loader wave per K-step
+  constexpr int WBYTES = LW * 32 * 128;
+  constexpr int WST = 4, PF = WST - 1;
+  constexpr int WBASE = 2 * XBYTES;
+  static_assert(BM % 64 == 0 && BN % 16 == 0, "tile");
+  static_assert((NI + MI) * 8 + NI * MI * 4 <= 200, "fragment double-buffering needs the registers");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int H = p.Hi, W = p.Wi;
+  const int tpx = W / PW, tpi = (H / PH) * tpx;       // patches per row / per image
+  const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;   // patches fastest: an XCD's run of tiles shares one weight panel in L2
+  const int b = tm / tpi, trem = tm - b * tpi;
+  const int y0 = (trem / tpx) * PH, x0 = (trem % tpx) * PW;
+  const int n0 = tn * BN;
+  const int z = blockIdx.z;
+  const int nch = p.Cin >> 6;
+  const int c0 = z * p.nk_per_split;
+  const int c1 = min(nch, c0 + p.nk_per_split);
+  const int nsteps = (c1 - c0) * 9;
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  if (wave_all >= 4) {
+    // ------------------------------------------------------------------ loader waves
+    if (nsteps <= 0) return;
+    const int lw = wave_all - 4;
+    const int lrow = lane >> 3, pc = lane & 7;
+    const char* xsrc[LXW];
+    int xinc[LXW];
+#pragma unroll
+    for (int q = 0; q < LXW; ++q) {
+      const int hr = (q * 4 + lw) * 8 + lrow;
+      const int cl = pc ^ ((hr >> 1) & 7);
+      const int hy = hr / HWD, hx = hr - hy * HWD;
+      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      const bool ok = hr < XREAL && y >= 0 && y < H && x >= 0 && x < W;
+      xsrc[q] = ok ? reinterpret_cast<const char*>(p.x) + (((long)(b * H + y) * W + x) * p.ldx + c0 * 64 + cl * 8) * 2 : zero;
+      xinc[q] = ok ? 128 : 0;
+    }
+    const char* wsrc[LW];
+    bool wok[LW];
+#pragma unroll
+    for (int q = 0; q < LW; ++q) {
+      const int wr = (q * 4 + lw) * 8 + lrow;
+      const int cl = pc ^ ((wr >> 1) & 7);
+      const int n = n0 + wr;
+      wok[q] = wr < BN && n < p.N;
+      wsrc[q] = reinterpret_cast<const char*>(p.w) + ((size_t)(wok[q] ? n : 0) * p.ldw + cl * 8) * 2;
+    }
+    auto issue_x = [&](int buf) {
+      char* dst = smem + buf * XBYTES + lw * 1024;
+#pragma unroll
+      for (int q = 0; q < LXW; ++q) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xsrc[q],
+                                         (__attribute__((address_space(3))) void*)(dst + q * 4096), 16, 0, 0);
+        xsrc[q] += xinc[q];
+      }
+    };
+    int st_tap = 0, st_ch = c0;                        // K-step the next issue_w stages
+    auto issue_w = [&](int slot) {
+      char* dst = smem + WBASE + slot * WBYTES + lw * 1024;
+      const long koff = ((long)st_tap * p.Cin + (st_ch << 6)) * 2;
+#pragma unroll
+      for (int q = 0; q < LW; ++q) {
+        const char* src = wok[q] ? wsrc[q] + koff : zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + q * 4096), 16, 0, 0);
+      }
+      if (++st_tap == 9) { st_tap = 0; ++st_ch; }
+    };
+    issue_x(0);
+#pragma unroll
+    for (int s = 0; s < PF; ++s) issue_w(s);           // nsteps >= 9 > PF
+    int tap = 0, cr = 0;                               // tap / relative Cin slice of K-step `it`
+    const int ncr = c1 - c0;
+    for (int it = 0; it < nsteps; ++it) {
+      // retire W(it) (and, being older, the patch of its slice).  Younger DMAs may stay in flight: the W stages of the next
+      // min(PF-1, remaining) steps, plus the next slice's patch when it was issued in one of the last PF-1 iterations.
+      const int a = min(PF - 1, nsteps - 1 - it);
+      const bool xin = (tap == 1 || tap == 2) && cr + 1 < ncr;
+      if (xin) {
+        if (a >= 2) wait_vmcnt<2 * LW + LXW>();
+        else if (a == 1) wait_vmcnt<LW + LXW>();
+        else wait_vmcnt<LXW>();
+      } else {
+        if (a >= 2) wait_vmcnt<2 * LW>();
+        else if (a == 1) wait_vmcnt<LW>();
+        else wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      // every MFMA wave now holds K-step it-1 in registers: its W slot and (at tap 0) the previous slice's patch are free
+      if (tap == 0 && cr + 1 < ncr) issue_x((cr + 1) & 1);
+      if (it + PF < nsteps) issue_w((it + PF) % WST);
+      if (++tap == 9) { tap = 0; ++cr; }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- MFMA waves
+  const int wave = wave_all;
+  const int frow = lane & 15, fq = lane >> 4;
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // bias prefetch (keeps the epilogue from starting with a dependent global round trip) only where the registers allow
+  constexpr bool BPRE = NI <= 5;
+  f32x4 bpre[NI];
+  const bool use_bpre = BPRE && p.bias && !p.bias_per_row && p.splitk == 1;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int n = n0 + i * 16 + fq * 4;
+    bpre[i] = (use_bpre && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  // patch fragment offsets (k-half 0) of this lane's pixel in each of its 16-pixel groups, for the nine taps;
+  // k-half 1 is logical chunk 4 + fq = the same offset with byte bit 6 flipped
+  unsigned xrel[9][MI];
+  int mrow[MI];
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    const int pi = (wave * MI + j) * 16 + frow;
+    const int py = pi / PW, px = pi - py * PW;
+    mrow[j] = (b * H + y0 + py) * W + x0 + px;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int hr = (py + t / 3) * HWD + px + t % 3;
+      xrel[t][j] = hr * 128 + ((fq ^ ((hr >> 1) & 7)) << 4);
+    }
+  }
+  const int swl = (frow >> 1) & 7;
+  const unsigned wa0 = lds0 + WBASE + frow * 128 + ((fq ^ swl) << 4), wa1 = lds0 + WBASE + frow * 128 + (((4 + fq) ^ swl) << 4);
+
+  if (nsteps > 0) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // retire the kernel-argument loads: see conv_gemm.hip (partial lgkmcnt waits below)
+    f16x8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
+    auto reads0 = [&](auto T, unsigned wsl, unsigned xoff) {
+      static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wf0[I.value], wa0 + wsl); });
+      static_for<MI>([&](auto J) { lds_read128<0>(xf0[J.value], lds0 + xoff + xrel[T.value][J.value]); });
+    };
+    auto reads1 = [&](auto T, unsigned wsl, unsigned xoff) {
+      static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wf1[I.value], wa1 + wsl); });
+      static_for<MI>([&](auto J) { lds_read128<0>(xf1[J.value], lds0 + xoff + (xrel[T.value][J.value] ^ 64u)); });
+    };
+    auto mma_half = [&](const f16x8 (&wf)[NI], const f16x8 (&xf)[MI]) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    };
+    __builtin_amdgcn_s_barrier();            // K-step 0 (and the first patch) visible
+    reads0(std::integral_constant<int, 0>{}, 0u, 0u);
+    reads1(std::integral_constant<int, 0>{}, 0u, 0u);
+    int it = 0;
+    unsigned slot = 0;                       // W ring slot of K-step `it`
+    for (int cr = 0; cr < c1 - c0; ++cr) {
+      const unsigned xcur = (cr & 1) * XBYTES;
+      static_for<9>([&](auto T) {
+        constexpr int NT = (T.value + 1) % 9;                     // tap of the next K-step
+        const bool more = it + 1 < nsteps;
+        const unsigned nslot = (slot + 1) & (WST - 1);
+        const unsigned xnext = T.value == 8 ? (unsigned)XBYTES - xcur : xcur;
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NI + MI) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(wf0, xf0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+          __builtin_amdgcn_s_barrier();      // K-step it+1 visible; every MFMA wave holds K-step `it` in registers
+          reads0(std::integral_constant<int, NT>{}, nslot * WBYTES, xnext);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(wf1, xf1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) reads1(std::integral_constant<int, NT>{}, nslot * WBYTES, xnext);
+        slot = nslot;
+        ++it;
+      });
+    }
+  }
+  epilogue_rows<NI, MI, BN>(p, acc, mrow, n0, fq, z, bpre, use_bpre);
+}
+
+// ------------------------------------------------------------------------------------------------
+// variants + launcher
+// ------------------------------------------------------------------------------------------------
+const HaloCfg kHaloCfgs[] = {
+    {8, 16, 80, "conv3x3_halo_kernel<8,16,80>"},
+    {8, 16, 160, "conv3x3_halo_kernel<8,16,160>"},
+    {8, 8, 80, "conv3x3_halo_kernel<8,8,80>"},
+    {8, 8, 160, "conv3x3_halo_kernel<8,8,160>"},
+    {8, 16, 64, "conv3x3_halo_kernel<8,16,64>"},
+    {8, 16, 128, "conv3x3_halo_kernel<8,16,128>"},
+};
+const int kNumHaloCfgs = 6;
+
+template <int PH, int PW, int BN>
+static int launch_halo_t(const KP& kp, int tiles_m, int tiles_n, hipStream_t stream) {
+  constexpr int LXW = ((PH + 2) * (PW + 2) + 31) / 32, LW = (BN + 31) / 32;
+  constexpr int smem = 2 * LXW * 32 * 128 + 4 * LW * 32 * 128;
+  static_assert(smem <= 160 * 1024, "LDS");
+  static bool done = false;
+  if (!done) {
+    SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<PH, PW, BN>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    done = true;
+  }
+  hipLaunchKernelGGL((conv3x3_halo_kernel<PH, PW, BN>), dim3(tiles_m * tiles_n, 1, kp.splitk), dim3(512), smem, stream, kp);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_halo(int variant, const KP& kp, int tiles_m, int tiles_n, hipStream_t stream) {
+  switch (variant) {
+    case 0: return launch_halo_t<8, 16, 80>(kp, tiles_m, tiles_n, stream);
+    case 1: return launch_halo_t<8, 16, 160>(kp, tiles_m, tiles_n, stream);
+    case 2: return launch_halo_t<8, 8, 80>(kp, tiles_m, tiles_n, stream);
+    case 3: return launch_halo_t<8, 8, 160>(kp, tiles_m, tiles_n, stream);
+    case 4: return launch_halo_t<8, 16, 64>(kp, tiles_m, tiles_n, stream);
+    case 5: return launch_halo_t<8, 16, 128>(kp, tiles_m, tiles_n, stream);
+    default: return fail("launch_halo: bad variant %d", variant);
+  }
+}
+
+}  // namespace sdeo

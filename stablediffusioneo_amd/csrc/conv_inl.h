@@ -1,0 +1,161 @@
+// Device-side pieces shared by the implicit-GEMM kernels (conv_gemm.hip) and the halo-reuse 3x3 kernel (conv_halo.hip):
+// kernel parameter block, epilogue, XCD-aware tile order, LDS-DMA / fragment-read helpers.
+#pragma once
+#include <utility>
+
+#include "kernels.h"
+
+namespace sdeo {
+
+struct KP {
+  const f16* x;
+  const f16* w;
+  f16* y;
+  float* y32;
+  const float* bias;
+  const float* bias2;
+  const f16* res;
+  float* ws;
+  int M, N, K;
+  int Hi, Wi, Cin, Ho, Wo, S, stride, pad, ups;
+  int HoWo;
+  int ldx, ldw, ldy, ldres, ld_bias2;
+  int act, bias_per_row;
+  float scale;
+  int nk, nk_per_split, splitk;
+  int tiles_m, tiles_n;
+  // SDEO_DBG_GEMM (measurement only, results are wrong): 1 = activation DMAs read the zero page, 2 = weight DMAs do,
+  // 4 = no MFMAs, 8 = no DMAs after the prologue, 16 = no fragment reads, 32 = no epilogue
+  int dbg;
+  int n_fastest;     // tile order inside an XCD's contiguous run: 1 = all N tiles of an M tile are neighbours
+};
+
+// 256 bytes of zeros: DMA source for padded / out-of-range rows
+static __device__ __attribute__((aligned(256))) const unsigned int g_zero_page[64] = {0};
+
+template <int BK>
+__device__ __forceinline__ int swz_chunk(int row, int chunk) {
+  // conflict-free for the 16-lane groups of ds_read_b128 when lanes read rows r..r+15 at one k-chunk
+  if (BK == 64) return chunk ^ ((row >> 1) & 7);
+  return chunk ^ (((row >> 3) & 1) * 3);
+}
+
+// ---- epilogue shared by all kernels: lane holds n = nb + i*16 + fq*4 + {0..3} (4 consecutive channels) of output row
+//      mrow[j] (-1: no such row) for accumulator tile (i, j); nb = first column of this wave's TN-wide strip
+template <int NI, int MI, int TN>
+__device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI], const int (&mrow)[MI], int nb, int fq, int z,
+                                              const f32x4 (&bpre)[NI], bool use_bpre) {
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    const int m = mrow[j];
+    if (m < 0) continue;
+    if constexpr (NI % 2 == 0 && TN % 32 == 0) {
+      if (p.act == 3) {
+        // GEGLU (`attention.py:49-56`) fused into ff.net.0.proj: the weight rows were interleaved at load time in blocks of
+        // 16 (block 2q = value channels 16q..16q+15, block 2q+1 = their gates), so accumulator tiles i and i+1 hold, in the
+        // same lane and register, a value and its gate.  Output column = value channel; ldy counts N/2 columns.
+#pragma unroll
+        for (int i = 0; i < NI; i += 2) {
+          const int n = nb + i * 16 + fq * 4;
+          if (n >= p.N) continue;
+          f32x4 v = acc[i][j], g = acc[i + 1][j];
+          if (p.bias) {
+            if (use_bpre) { v += bpre[i]; g += bpre[i + 1]; }
+            else { v += *reinterpret_cast<const f32x4*>(p.bias + n); g += *reinterpret_cast<const f32x4*>(p.bias + n + 16); }
+          }
+          f16x4 o;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) o[t] = (f16)(v[t] * gelu_erf_f(g[t]));
+          *reinterpret_cast<f16x4*>(p.y + (size_t)m * p.ldy + ((nb + i * 16) >> 1) + fq * 4) = o;
+        }
+        continue;
+      }
+    }
+    const int b = p.bias2 ? m / p.HoWo : 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int n = nb + i * 16 + fq * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      if (p.splitk > 1) {
+        *reinterpret_cast<f32x4*>(p.ws + ((size_t)z * p.M + m) * p.N + n) = v;
+        continue;
+      }
+      if (p.bias) {
+        if (p.bias_per_row) v += p.bias[m];
+        else if (use_bpre) v += bpre[i];
+        else v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      }
+      if (p.bias2) v += *reinterpret_cast<const f32x4*>(p.bias2 + (size_t)b * p.ld_bias2 + n);
+      if (p.act == 1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = quick_gelu_f(v[t]);
+      }
+      v *= p.scale;
+      if (p.res) {
+        const f16x4 r = *reinterpret_cast<const f16x4*>(p.res + (size_t)m * p.ldres + n);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] += (float)r[t];
+      }
+      if (p.y32) {
+        *reinterpret_cast<f32x4*>(p.y32 + (size_t)m * p.ldy + n) = v;
+      } else {
+        f16x4 o;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = (f16)v[t];
+        *reinterpret_cast<f16x4*>(p.y + (size_t)m * p.ldy + n) = o;
+      }
+    }
+  }
+}
+
+// implicit-GEMM tiles: accumulator tile (i, j) of wave (wm, wn) is output row m0 + wm*TM + j*16 + frow
+template <int NI, int MI, int TM, int TN>
+__device__ __forceinline__ void epilogue(const KP& p, f32x4 (&acc)[NI][MI], int m0, int n0, int wm, int wn, int frow, int fq, int z,
+                                         const f32x4 (&bpre)[NI], bool use_bpre) {
+  int mrow[MI];
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    const int m = m0 + wm * TM + j * 16 + frow;
+    mrow[j] = m < p.M ? m : -1;
+  }
+  epilogue_rows<NI, MI, TN>(p, acc, mrow, n0 + wn * TN, fq, z, bpre, use_bpre);
+}
+
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (observed, speed only), so give each
+// XCD a contiguous run of tiles (bijective for any tile count): neighbouring tiles share a weight panel in L2.
+__device__ __forceinline__ int xcd_remap(int wg, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// compile-time loop (the LDS offsets of the inline-asm fragment reads must be immediates)
+template <int N, typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read128(f16x8& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+
+// halo-reuse 3x3 kernel family (conv_halo.hip): variant table + launcher used by conv_gemm's planner
+struct HaloCfg { int ph, pw, bn; const char* name; };
+extern const HaloCfg kHaloCfgs[];
+extern const int kNumHaloCfgs;
+int launch_halo(int variant, const KP& kp, int tiles_m, int tiles_n, hipStream_t stream);
+
+}  // namespace sdeo

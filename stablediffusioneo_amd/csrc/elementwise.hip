@@ -240,6 +240,35 @@ int f32_to_f16(f16* y, const float* x, int64_t n, hipStream_t stream) {
   return 0;
 }
 
+// GEGLU weight interleave (load time): row j of the [2H][cols] projection (`attention.py:49-56`: rows 0..H-1 = values,
+// H..2H-1 = gates) goes to row 32*(j'/16) + 16*is_gate + j'%16 with j' = j mod H, so that the GEMM epilogue finds a value
+// and its gate in neighbouring 16-wide accumulator tiles of the same lane.  cols = 1 with OUT = float handles the bias.
+template <typename OUT>
+__global__ __launch_bounds__(256) void geglu_interleave_kernel(OUT* __restrict__ y, const float* __restrict__ x, int H, int64_t cols) {
+  const int64_t n = (int64_t)2 * H * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int j = (int)(i / cols);
+    const int64_t c = i - (int64_t)j * cols;
+    const int gate = j >= H, jj = gate ? j - H : j;
+    const int dst = 32 * (jj >> 4) + 16 * gate + (jj & 15);
+    y[(int64_t)dst * cols + c] = (OUT)x[i];
+  }
+}
+
+int geglu_interleave_f32_to_f16(f16* y, const float* x, int H, int cols, hipStream_t stream) {
+  SDEO_CHECK(y && x && H > 0 && H % 16 == 0 && cols > 0, "geglu_interleave: bad operand (H=%d must be a multiple of 16)", H);
+  hipLaunchKernelGGL(geglu_interleave_kernel<f16>, grid_for((int64_t)2 * H * cols), dim3(256), 0, stream, y, x, H, (int64_t)cols);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+int geglu_interleave_f32(float* y, const float* x, int H, hipStream_t stream) {
+  SDEO_CHECK(y && x && H > 0 && H % 16 == 0, "geglu_interleave: bad operand (H=%d must be a multiple of 16)", H);
+  hipLaunchKernelGGL(geglu_interleave_kernel<float>, grid_for((int64_t)2 * H), dim3(256), 0, stream, y, x, H, (int64_t)1);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
 // CFG combine + DDIM update (`cldm/ddim_hacked.py:192,208-231`), eps-parameterisation, fp32 NCHW latents.
 //   e = eps_u + s*(eps_c - eps_u);  pred_x0 = (x - sqrt(1-a_t) e)/sqrt(a_t)
 //   x_prev = sqrt(a_prev) pred_x0 + sqrt(1 - a_prev - sigma^2) e + sigma * noise

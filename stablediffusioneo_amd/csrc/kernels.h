@@ -27,7 +27,8 @@ struct ConvGemm {
   int Ho = 1, Wo = 1, R = 1, S = 1, stride = 1, pad = 0;
   int ups = 0;                 // 1: the conv sees the source nearest-upsampled x2 (Upsample folded in)
   int ldx = 0, ldw = 0, ldy = 0, ldres = 0, ld_bias2 = 0;
-  int act = 0;                 // 0 none, 1 SiLU, 2 quick-GELU  v * sigmoid(1.702 v)  (CLIP MLP)
+  int act = 0;                 // 0 none, 1 SiLU, 2 quick-GELU  v * sigmoid(1.702 v)  (CLIP MLP),
+                               // 3 GEGLU pair: W rows interleaved value/gate in blocks of 16, y gets N/2 columns v * gelu(g)
   int bias_per_row = 0;
   float scale = 1.0f;
   int force_tile = -1;         // testing hook: tile config index
@@ -93,6 +94,9 @@ int oihw_f32_to_ohwi_f16(f16* y, const float* w, int O, int I, int R, int S, int
 int zero_f16(f16* y, int64_t n, hipStream_t stream);
 int f32_to_f16(f16* y, const float* x, int64_t n, hipStream_t stream);
 int f16_to_f32(float* y, const f16* x, int64_t n, hipStream_t stream);
+// GEGLU projection [2H][cols] fp32 -> fp16 with value / gate rows interleaved in blocks of 16 (see conv_gemm act = 3); bias variant
+int geglu_interleave_f32_to_f16(f16* y, const float* x, int H, int cols, hipStream_t stream);
+int geglu_interleave_f32(float* y, const float* x, int H, hipStream_t stream);
 // CLIP text embeddings: out[(b*T + t)][0:W] = tok_emb[ids[b*T + t]][0:W] + pos_emb[t][0:W]   (ids are clamped to [0, vocab))
 int embed_tokens(f16* out, const int32_t* ids, const f16* tok_emb, const f16* pos_emb, int B, int T, int W, int vocab,
                  hipStream_t stream);

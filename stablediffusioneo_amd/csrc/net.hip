@@ -123,7 +123,7 @@ static std::vector<HintConv> hint_convs(const sdeo_config& c) {
 // ------------------------------------------------------------------------------------------------
 // weights
 // ------------------------------------------------------------------------------------------------
-enum WKind { W_CONV, W_LINEAR, W_VEC };
+enum WKind { W_CONV, W_LINEAR, W_VEC, W_GEGLU_W, W_GEGLU_B };   // W_GEGLU_*: ff.net.0.proj, value / gate rows interleaved
 struct WEntry {
   std::string name;
   int64_t dims[4];
@@ -322,7 +322,8 @@ static void reg_attn(Registry& r, const std::string& ns, const Blk& b, int ctx) 
   r.lin(t + ".attn2.to_k", ctx, c, false);
   r.lin(t + ".attn2.to_v", ctx, c, false);
   r.lin(t + ".attn2.to_out.0", c, c, true);
-  r.lin(t + ".ff.net.0.proj", c, 8 * c, true);
+  r.add(t + ".ff.net.0.proj.weight", W_GEGLU_W, {8 * c, c}, r.take((size_t)8 * c * c * 2));
+  r.add(t + ".ff.net.0.proj.bias", W_GEGLU_B, {8 * c}, r.take((size_t)8 * c * 4));
   r.lin(t + ".ff.net.2", 4 * c, c, true);
   r.norm(t + ".norm1", c);
   r.norm(t + ".norm2", c);
@@ -659,14 +660,13 @@ static T build_attn(Builder& b, const std::string& ns, const Blk& blk, const T& 
   b.release(tok1);
   // GEGLU feed-forward
   T a3 = b.ln(tok2, t + ".norm3");
-  T ff = b.gemm(a3, b.wptr(t + ".ff.net.0.proj.weight"), C, 8 * C, b.vptr(t + ".ff.net.0.proj.bias"));
-  b.release(a3);
+  // ff.net.0.proj + GEGLU in one launch (act 3: value * gelu(gate) in the GEMM epilogue, 4C columns out)
   T gg = b.alloc(x.n, x.h, x.w, 4 * C);
   {
-    f16* yp = gg.p; const f16* ap = ff.p; const int rows = x.rows();
-    b.push([=](hipStream_t s) { return geglu(yp, 4 * C, ap, 8 * C, rows, 4 * C, s); });
+    Builder::CO og; og.act = 3; og.out = &gg;
+    b.gemm(a3, b.wptr(t + ".ff.net.0.proj.weight"), C, 8 * C, b.vptr(t + ".ff.net.0.proj.bias"), og);
   }
-  b.release(ff);
+  b.release(a3);
   Builder::CO r3; r3.res = &tok2;
   T tok3 = b.gemm(gg, b.wptr(t + ".ff.net.2.weight"), 4 * C, C, b.vptr(t + ".ff.net.2.bias"), r3);
   b.release(gg);
@@ -1168,6 +1168,8 @@ int sdeo_load_weight(sdeo_handle h, const char* name, const float* host_data, co
       break;
     case W_LINEAR: rc = f32_to_f16((f16*)dst, h->stage, (int64_t)n, 0); break;
     case W_VEC: SDEO_HIP(hipMemcpy(dst, h->stage, n * sizeof(float), hipMemcpyDeviceToDevice)); break;
+    case W_GEGLU_W: rc = geglu_interleave_f32_to_f16((f16*)dst, h->stage, (int)(w.dims[0] / 2), (int)w.dims[1], 0); break;
+    case W_GEGLU_B: rc = geglu_interleave_f32((float*)dst, h->stage, (int)(w.dims[0] / 2), 0); break;
   }
   if (rc) return rc;
   SDEO_HIP(hipDeviceSynchronize());

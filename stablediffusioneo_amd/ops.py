@@ -84,6 +84,31 @@ def gemm(x, w, bias=None, res=None, act=0, scale=1.0, out_f32=False, bias_per_ro
     return y
 
 
+def geglu_interleave(w):
+    """Row order the GEGLU-fused projection expects (same map as the load-time kernel `geglu_interleave_kernel`):
+    [2H][...] with rows 0..H-1 = values, H..2H-1 = gates -> blocks of 16 alternating value / gate."""
+    h = w.shape[0] // 2
+    assert h % 16 == 0
+    v = w[:h].reshape(h // 16, 1, 16, *w.shape[1:])
+    g = w[h:].reshape(h // 16, 1, 16, *w.shape[1:])
+    return torch.cat([v, g], 1).reshape(w.shape).contiguous()
+
+
+def gemm_geglu(x, w_interleaved, bias_interleaved=None):
+    """y[m][0:H] = (x w_v^T + b_v) * gelu_erf(x w_g^T + b_g): ff.net.0.proj + GEGLU (`attention.py:49-56`) in one launch.
+    Weights / bias already in `geglu_interleave` order."""
+    lib = _lib.load()
+    _need_cuda(x, w_interleaved)
+    m, k = x.shape
+    n, k2 = w_interleaved.shape
+    assert k == k2 and n % 32 == 0 and x.stride(1) == 1 and w_interleaved.stride(1) == 1
+    y = torch.empty((m, n // 2), dtype=torch.float16, device=x.device)
+    check(lib.sdeo_gemm_f16(ptr(y), _i(n // 2), ptr(x), _i(x.stride(0)), ptr(w_interleaved), _i(w_interleaved.stride(0)),
+                            ptr(bias_interleaved), None, _i(0), _i(m), _i(n), _i(k), _i(3), _f(1.0), _i(0), _i(0), None,
+                            C.c_size_t(0), cur_stream()), "gemm_geglu")
+    return y
+
+
 def layernorm(x, gamma, beta, eps=1e-5):
     lib = _lib.load()
     _need_cuda(x, gamma, beta)

@@ -164,6 +164,64 @@ def test_conv2d_every_dma_tile(ops, tile, sk):
         lib.sdeo_debug_force_gemm_plan(C.c_int(-1), C.c_int(0))
 
 
+HALO_TILES = {13: (8, 16, 80), 14: (8, 16, 160), 15: (8, 8, 80), 16: (8, 8, 160), 17: (8, 16, 64), 18: (8, 16, 128)}   # kTiles index -> (PH, PW, BN)
+
+
+@pytest.mark.parametrize("tile", sorted(HALO_TILES))
+@pytest.mark.parametrize("sk", [1, 2, 5])
+def test_conv2d_every_halo_tile(ops, tile, sk):
+    """halo-reuse 3x3 kernel (csrc/conv_halo.hip), every variant forced, with and without split-K: images of one and of
+    several patches (padding at all four borders and patch seams), ragged N, N smaller than the tile, Cin of 1..5
+    64-channel slices, bias + time-embedding + SiLU + residual epilogue."""
+    import ctypes as C
+    from stablediffusioneo_amd import _lib
+    lib = _lib.load()
+    lib.sdeo_debug_conv2d_kernel_name.restype = C.c_char_p
+    ph, pw, bn = HALO_TILES[tile]
+    try:
+        lib.sdeo_debug_force_gemm_plan(C.c_int(tile), C.c_int(sk))
+        for (n, cin, h, w, cout) in [(2, 320, 2 * ph, 2 * pw, 320), (1, 64, ph, pw, 72), (2, 128, 3 * ph, pw, 164), (1, 192, ph, 3 * pw, 640)]:
+            name = lib.sdeo_debug_conv2d_kernel_name(C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(cin), C.c_int(cout), C.c_int(3),
+                                                     C.c_int(1), C.c_int(0)).decode()
+            assert name == f"conv3x3_halo_kernel<{ph},{pw},{bn}>", name
+            x = h16(randn((n, cin, h, w), 240 + cin))
+            wt = h16(randn((cout, cin, 3, 3), 241) * (1.0 / (cin * 9)) ** 0.5)
+            bias = 0.1 * randn((cout,), 242)
+            bias2 = 0.3 * randn((n, cout), 243)
+            res = h16(randn((n, cout, h, w), 244))
+            ref = F.silu(F.conv2d(x.float(), wt.float(), bias, padding=1) + bias2[:, :, None, None]) * 0.825 + res.float()
+            y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), wt.permute(0, 2, 3, 1).contiguous().to(DEV),
+                                bias.to(DEV), bias2.to(DEV), res.permute(0, 2, 3, 1).contiguous().to(DEV), act=1, scale=0.825)
+            assert_close(y.permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3, what=f"halo tile {tile} sk {sk} conv {(n, cin, h, w, cout)}")
+    finally:
+        lib.sdeo_debug_force_gemm_plan(C.c_int(-1), C.c_int(0))
+
+
+def test_halo_plan_falls_back_when_ineligible(ops):
+    """a forced halo plan on a problem the kernel does not cover (stride 2, image not a multiple of the patch, 1x1) must fall
+    back to the implicit-GEMM kernels, never launch the halo kernel on it"""
+    import ctypes as C
+    from stablediffusioneo_amd import _lib
+    lib = _lib.load()
+    lib.sdeo_debug_conv2d_kernel_name.restype = C.c_char_p
+    try:
+        lib.sdeo_debug_force_gemm_plan(C.c_int(13), C.c_int(1))
+        for (n, cin, h, w, cout, k, stride, ups) in [(2, 320, 32, 32, 320, 3, 2, 0), (1, 128, 12, 20, 64, 3, 1, 0), (2, 960, 16, 16, 320, 1, 1, 0),
+                                                     (2, 640, 16, 16, 640, 3, 1, 1)]:
+            name = lib.sdeo_debug_conv2d_kernel_name(C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(cin), C.c_int(cout), C.c_int(k),
+                                                     C.c_int(stride), C.c_int(ups)).decode()
+            assert name.startswith("conv_gemm_"), name
+            x = h16(randn((n, cin, h, w), 250 + cin))
+            wt = h16(randn((cout, cin, k, k), 251) * (1.0 / (cin * k * k)) ** 0.5)
+            xin = F.interpolate(x.float(), scale_factor=2, mode="nearest") if ups else x.float()
+            ref = F.conv2d(xin, wt.float(), None, stride=stride, padding=k // 2)
+            y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), wt.permute(0, 2, 3, 1).contiguous().to(DEV),
+                                stride=stride, upsample2x=bool(ups))
+            assert_close(y.permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3, what=f"fallback conv {(n, cin, h, w, cout, k, stride, ups)}")
+    finally:
+        lib.sdeo_debug_force_gemm_plan(C.c_int(-1), C.c_int(0))
+
+
 def test_krsc_transform(ops):
     w = randn((24, 4, 3, 3), 220)
     y = ops.krsc_from_oihw(w.to(DEV), 8).cpu()
@@ -206,6 +264,20 @@ def test_gemm_f32_out_bias_per_row(ops):
     y = ops.gemm(x.to(DEV), w.to(DEV), bias.to(DEV), out_f32=True, bias_per_row=True)
     assert y.dtype == torch.float32
     assert_close(y, ref, rtol=1e-4, atol=1e-4, what="gemm f32 out")
+
+
+@pytest.mark.parametrize("m,c", [(8192, 320), (2048, 640), (512, 1280), (128, 1280), (130, 64), (77, 32)])
+def test_gemm_geglu_fused(ops, m, c):
+    """FeedForward's first half (`attention.py:49-76`): Linear(c -> 8c), chunk, x * gelu(gate), as ONE launch with the
+    value / gate rows interleaved; reference is the unfused fp32 torch expression on the ORIGINAL row order."""
+    x = h16(randn((m, c), 330 + c))
+    w = h16(randn((8 * c, c), 331) * (1.0 / c) ** 0.5)
+    bias = 0.1 * randn((8 * c,), 332)
+    val, gate = F.linear(x.float(), w.float(), bias).chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    y = ops.gemm_geglu(x.to(DEV), ops.geglu_interleave(w).to(DEV), ops.geglu_interleave(bias).to(DEV))
+    assert y.shape == (m, 4 * c)
+    assert_close(y, ref, rtol=2e-3, atol=3e-3, what=f"gemm+geglu {m}x{8 * c}x{c}")
 
 
 # ------------------------------------------------------------------ LayerNorm / GEGLU / timestep embedding
