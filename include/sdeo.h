@@ -53,6 +53,9 @@ const char* sdeo_tuned_gemm_plans_json(void);
 /* y = silu(x) on n fp16 elements: launch-floor probe for tools/launch_floor.py */
 /* name of the kernel instantiation sdeo_conv2d_nhwc_f16 would launch for this problem (plan table / forced plan / heuristic) */
 const char* sdeo_debug_conv2d_kernel_name(int n, int h, int w, int cin, int cout, int ksize, int stride, int upsample2x);
+/* measurement only (SDEO_DBG_GEMM bit 6): per-workgroup phase stamps of the last GEMM (which = 0) / halo conv (1) launch,
+ * 8 x uint64 per workgroup in 10 ns units */
+int sdeo_debug_read_stamps(int which, unsigned long long* out, int n);
 int sdeo_debug_silu(void* y, const void* x, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------ op-level entry points (used by tests)

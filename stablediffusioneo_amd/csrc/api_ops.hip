@@ -70,6 +70,10 @@ size_t sdeo_conv2d_workspace_bytes(int n, int h, int w, int cin, int cout, int k
   return conv_gemm_workspace_bytes(p);
 }
 
+int sdeo_debug_read_stamps(int which, unsigned long long* out, int n) {
+  return which ? conv_halo_read_stamps(out, n) : conv_gemm_read_stamps(out, n);
+}
+
 const char* sdeo_debug_conv2d_kernel_name(int n, int h, int w, int cin, int cout, int ksize, int stride, int upsample2x) {
   ConvGemm p;
   if (fill_conv(p, n, h, w, cin, cout, ksize, stride, upsample2x)) return "";

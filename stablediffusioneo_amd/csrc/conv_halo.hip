@@ -18,18 +18,31 @@
 
 namespace sdeo {
 
-template <int PH, int PW, int BN>
-__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const KP p) {
+constexpr int halo_xbytes(int ph, int pw) { return ((ph + 2) * (pw + 2) + 31) / 32 * 32 * 128; }
+constexpr int halo_wbytes(int bn) { return (bn + 31) / 32 * 32 * 128; }
+constexpr int halo_stages(int ph, int pw, int bn) {
+  const int s = (160 * 1024 - 2 * halo_xbytes(ph, pw)) / halo_wbytes(bn);
+  return s > 8 ? 8 : s;
+}
+
+// NMW = 4: one MFMA wave per SIMD beside one loader wave.  NMW = 8: two MFMA waves per SIMD (waves w and w + 4 share one), each
+// owning half as many pixels: an in-order wave alone on its SIMD exposes every fragment-read issue, wait and barrier between
+// its MFMA batches (measured 740 clocks per K-step for 320 clocks of MFMA); with a partner the SIMD interleaves the two.
+template <int PH, int PW, int BN, int NMW>
+__global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP p) {
   constexpr int BM = PH * PW;
-  constexpr int MI = BM / 64, NI = BN / 16;
+  constexpr int MI = BM / (16 * NMW), NI = BN / 16;
   constexpr int HWD = PW + 2, XREAL = (PH + 2) * HWD;
   constexpr int LXW = (XREAL + 31) / 32;             // patch DMAs per loader wave per Cin slice (8 rows each, 4 loader waves)
   constexpr int XBYTES = LXW * 32 * 128;
   constexpr int LW = (BN + 31) / 32;                 // weight DMAs per loader wave per K-step
   constexpr int WBYTES = LW * 32 * 128;
-  constexpr int WST = 4, PF = WST - 1;
+  // weight ring as deep as LDS allows (<= 8 slots).  What bounds a K-step here is bytes in flight per CU, not bandwidth: a DMA
+  // takes ~1 us to land under load, so a CU takes in (bytes in flight) / 1 us; 3 steps ahead gave ~40 GB/s, 7 give ~90.
+  constexpr int WST = halo_stages(PH, PW, BN), PF = WST - 1;
   constexpr int WBASE = 2 * XBYTES;
-  static_assert(BM % 64 == 0 && BN % 16 == 0, "tile");
+  static_assert(PF >= 2 && PF <= 8, "ring depth");
+  static_assert(BM % (16 * NMW) == 0 && BN % 16 == 0, "tile");
   static_assert((NI + MI) * 8 + NI * MI * 4 <= 200, "fragment double-buffering needs the registers");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -49,11 +62,17 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const KP p) {
   const int c1 = min(nch, c0 + p.nk_per_split);
   const int nsteps = (c1 - c0) * 9;
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  stamp(p, 0);
+  stamp_cycles(p, 14);
+  if ((p.dbg & 256) && lane == 0) {          // which SIMD each wave of the workgroup landed on (HW_REG_HW_ID)
+    const int wg = blockIdx.x + gridDim.x * blockIdx.z;
+    if (wg < kStampWGs) g_stamps[wg * kStampSlots + wave_all] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+  }
 
-  if (wave_all >= 4) {
+  if (wave_all >= NMW) {
     // ------------------------------------------------------------------ loader waves
-    if (nsteps <= 0) return;
-    const int lw = wave_all - 4;
+    if (nsteps <= 0) { __builtin_amdgcn_s_barrier(); return; }
+    const int lw = wave_all - NMW;
     const int lrow = lane >> 3, pc = lane & 7;
     const char* xsrc[LXW];
     int xinc[LXW];
@@ -106,23 +125,25 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const KP p) {
     for (int it = 0; it < nsteps; ++it) {
       // retire W(it) (and, being older, the patch of its slice).  Younger DMAs may stay in flight: the W stages of the next
       // min(PF-1, remaining) steps, plus the next slice's patch when it was issued in one of the last PF-1 iterations.
+      // (the patch is issued at tap 0 BEFORE that iteration's W stage, so it is younger than W(it) for taps 1 .. PF-1)
       const int a = min(PF - 1, nsteps - 1 - it);
-      const bool xin = (tap == 1 || tap == 2) && cr + 1 < ncr;
-      if (xin) {
-        if (a >= 2) wait_vmcnt<2 * LW + LXW>();
-        else if (a == 1) wait_vmcnt<LW + LXW>();
-        else wait_vmcnt<LXW>();
-      } else {
-        if (a >= 2) wait_vmcnt<2 * LW>();
-        else if (a == 1) wait_vmcnt<LW>();
-        else wait_vmcnt<0>();
+      const bool xin = tap >= 1 && tap <= PF - 1 && cr + 1 < ncr;
+      if (a == PF - 1) {
+        if (xin) wait_vmcnt<(PF - 1) * LW + LXW>();
+        else wait_vmcnt<(PF - 1) * LW>();
+      } else {                                           // the last PF-1 steps: nothing is issued any more (xin is false there
+        static_for<PF - 1>([&](auto A) {                 // unless the range has a single slice, where it is false anyway)
+          if (a == A.value) wait_vmcnt<A.value * LW>();
+        });
       }
       __builtin_amdgcn_s_barrier();
       // every MFMA wave now holds K-step it-1 in registers: its W slot and (at tap 0) the previous slice's patch are free
+      if (p.dbg & 8) { if (++tap == 9) { tap = 0; ++cr; } continue; }      // SDEO_DBG_GEMM ablation: no DMAs after the prologue
       if (tap == 0 && cr + 1 < ncr) issue_x((cr + 1) & 1);
       if (it + PF < nsteps) issue_w((it + PF) % WST);
       if (++tap == 9) { tap = 0; ++cr; }
     }
+    __builtin_amdgcn_s_barrier();            // matches the MFMA waves' pre-epilogue barrier
     return;
   }
 
@@ -168,21 +189,26 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const KP p) {
     __builtin_amdgcn_s_waitcnt(0xc07f);      // retire the kernel-argument loads: see conv_gemm.hip (partial lgkmcnt waits below)
     f16x8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
     auto reads0 = [&](auto T, unsigned wsl, unsigned xoff) {
+      if (p.dbg & 16) return;
       static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wf0[I.value], wa0 + wsl); });
       static_for<MI>([&](auto J) { lds_read128<0>(xf0[J.value], lds0 + xoff + xrel[T.value][J.value]); });
     };
     auto reads1 = [&](auto T, unsigned wsl, unsigned xoff) {
+      if (p.dbg & 16) return;
       static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wf1[I.value], wa1 + wsl); });
       static_for<MI>([&](auto J) { lds_read128<0>(xf1[J.value], lds0 + xoff + (xrel[T.value][J.value] ^ 64u)); });
     };
     auto mma_half = [&](const f16x8 (&wf)[NI], const f16x8 (&xf)[MI]) {
+      if (p.dbg & 4) return;
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < MI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     };
+    stamp(p, 1);
     __builtin_amdgcn_s_barrier();            // K-step 0 (and the first patch) visible
+    stamp(p, 2);
     reads0(std::integral_constant<int, 0>{}, 0u, 0u);
     reads1(std::integral_constant<int, 0>{}, 0u, 0u);
     int it = 0;
@@ -192,7 +218,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const KP p) {
       static_for<9>([&](auto T) {
         constexpr int NT = (T.value + 1) % 9;                     // tap of the next K-step
         const bool more = it + 1 < nsteps;
-        const unsigned nslot = (slot + 1) & (WST - 1);
+        const unsigned nslot = slot + 1 == WST ? 0u : slot + 1;
         const unsigned xnext = T.value == 8 ? (unsigned)XBYTES - xcur : xcur;
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NI + MI) : "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -213,46 +239,75 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const KP p) {
       });
     }
   }
-  epilogue_rows<NI, MI, BN>(p, acc, mrow, n0, fq, z, bpre, use_bpre);
+  // all fragment reads done, no DMA pending: the patch / ring LDS becomes the waves' private epilogue scratch
+  __builtin_amdgcn_s_barrier();
+  stamp(p, 3);
+  stamp_cycles(p, 15);
+  if (p.dbg & 32) return;
+  static_assert(NMW * epilogue_scratch_bytes(BN) <= 2 * XBYTES + WST * WBYTES, "epilogue scratch");
+  epilogue_rows<NI, MI, BN>(p, acc, mrow, n0, fq, z, bpre, use_bpre, smem + wave * epilogue_scratch_bytes(BN));
+  if (p.dbg & 64) {
+    stamp(p, 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(p, 5);
+    if (p.dbg & 128) {        // the same epilogue once more, now with its code resident: cold instruction fetch vs work
+      epilogue_rows<NI, MI, BN>(p, acc, mrow, n0, fq, z, bpre, use_bpre, smem + wave * epilogue_scratch_bytes(BN));
+      stamp(p, 6);
+    }
+  }
+}
+
+int conv_halo_read_stamps(unsigned long long* out, int n) {
+  SDEO_HIP(hipDeviceSynchronize());
+  SDEO_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)(n < kStampWGs * kStampSlots ? n : kStampWGs * kStampSlots)));
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
 // variants + launcher
 // ------------------------------------------------------------------------------------------------
 const HaloCfg kHaloCfgs[] = {
-    {8, 16, 80, "conv3x3_halo_kernel<8,16,80>"},
-    {8, 16, 160, "conv3x3_halo_kernel<8,16,160>"},
-    {8, 8, 80, "conv3x3_halo_kernel<8,8,80>"},
-    {8, 8, 160, "conv3x3_halo_kernel<8,8,160>"},
-    {8, 16, 64, "conv3x3_halo_kernel<8,16,64>"},
-    {8, 16, 128, "conv3x3_halo_kernel<8,16,128>"},
+    {8, 16, 80, "conv3x3_halo_kernel<8,16,80,4>"},
+    {8, 16, 160, "conv3x3_halo_kernel<8,16,160,4>"},
+    {8, 8, 80, "conv3x3_halo_kernel<8,8,80,4>"},
+    {8, 8, 160, "conv3x3_halo_kernel<8,8,160,4>"},
+    {8, 16, 64, "conv3x3_halo_kernel<8,16,64,4>"},
+    {8, 16, 128, "conv3x3_halo_kernel<8,16,128,4>"},
+    {8, 16, 80, "conv3x3_halo_kernel<8,16,80,8>"},
+    {8, 16, 160, "conv3x3_halo_kernel<8,16,160,8>"},
+    {8, 16, 64, "conv3x3_halo_kernel<8,16,64,8>"},
+    {8, 16, 128, "conv3x3_halo_kernel<8,16,128,8>"},
 };
-const int kNumHaloCfgs = 6;
+const int kNumHaloCfgs = 10;
 
-template <int PH, int PW, int BN>
+template <int PH, int PW, int BN, int NMW>
 static int launch_halo_t(const KP& kp, int tiles_m, int tiles_n, hipStream_t stream) {
-  constexpr int LXW = ((PH + 2) * (PW + 2) + 31) / 32, LW = (BN + 31) / 32;
-  constexpr int smem = 2 * LXW * 32 * 128 + 4 * LW * 32 * 128;
+  constexpr int smem = 2 * halo_xbytes(PH, PW) + halo_stages(PH, PW, BN) * halo_wbytes(BN);
   static_assert(smem <= 160 * 1024, "LDS");
   static bool done = false;
   if (!done) {
-    SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<PH, PW, BN>),
+    SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<PH, PW, BN, NMW>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     done = true;
   }
-  hipLaunchKernelGGL((conv3x3_halo_kernel<PH, PW, BN>), dim3(tiles_m * tiles_n, 1, kp.splitk), dim3(512), smem, stream, kp);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<PH, PW, BN, NMW>), dim3(tiles_m * tiles_n, 1, kp.splitk), dim3(NMW * 64 + 256), smem, stream,
+                     kp);
   SDEO_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_halo(int variant, const KP& kp, int tiles_m, int tiles_n, hipStream_t stream) {
   switch (variant) {
-    case 0: return launch_halo_t<8, 16, 80>(kp, tiles_m, tiles_n, stream);
-    case 1: return launch_halo_t<8, 16, 160>(kp, tiles_m, tiles_n, stream);
-    case 2: return launch_halo_t<8, 8, 80>(kp, tiles_m, tiles_n, stream);
-    case 3: return launch_halo_t<8, 8, 160>(kp, tiles_m, tiles_n, stream);
-    case 4: return launch_halo_t<8, 16, 64>(kp, tiles_m, tiles_n, stream);
-    case 5: return launch_halo_t<8, 16, 128>(kp, tiles_m, tiles_n, stream);
+    case 0: return launch_halo_t<8, 16, 80, 4>(kp, tiles_m, tiles_n, stream);
+    case 1: return launch_halo_t<8, 16, 160, 4>(kp, tiles_m, tiles_n, stream);
+    case 2: return launch_halo_t<8, 8, 80, 4>(kp, tiles_m, tiles_n, stream);
+    case 3: return launch_halo_t<8, 8, 160, 4>(kp, tiles_m, tiles_n, stream);
+    case 4: return launch_halo_t<8, 16, 64, 4>(kp, tiles_m, tiles_n, stream);
+    case 5: return launch_halo_t<8, 16, 128, 4>(kp, tiles_m, tiles_n, stream);
+    case 6: return launch_halo_t<8, 16, 80, 8>(kp, tiles_m, tiles_n, stream);
+    case 7: return launch_halo_t<8, 16, 160, 8>(kp, tiles_m, tiles_n, stream);
+    case 8: return launch_halo_t<8, 16, 64, 8>(kp, tiles_m, tiles_n, stream);
+    case 9: return launch_halo_t<8, 16, 128, 8>(kp, tiles_m, tiles_n, stream);
     default: return fail("launch_halo: bad variant %d", variant);
   }
 }

@@ -28,7 +28,26 @@ struct KP {
   // 4 = no MFMAs, 8 = no DMAs after the prologue, 16 = no fragment reads, 32 = no epilogue
   int dbg;
   int n_fastest;     // tile order inside an XCD's contiguous run: 1 = all N tiles of an M tile are neighbours
+  int coalesce;      // host-checked: the LDS-transposed 16-byte epilogue applies (see epilogue_rows)
 };
+
+// SDEO_DBG_GEMM bit 6 (64): per-workgroup phase stamps (s_memrealtime, 100 MHz, chip-wide) written by MFMA wave 0, lane 0:
+// [0] kernel entry, [1] address set-up done, [2] first K-step visible, [3] K loop done, [4] epilogue stores issued,
+// [5] stores complete.  One copy of the buffer per translation unit; read with sdeo_debug_read_stamps.
+constexpr int kStampWGs = 4096, kStampSlots = 16;
+static __device__ unsigned long long g_stamps[kStampWGs * kStampSlots];
+__device__ __forceinline__ void stamp_cycles(const KP& p, int slot) {      // shader-clock counter (for the in-kernel clock rate)
+  if ((p.dbg & 64) && threadIdx.x == 0) {
+    const int wg = blockIdx.x + gridDim.x * blockIdx.z;
+    if (wg < kStampWGs) g_stamps[wg * kStampSlots + slot] = __builtin_amdgcn_s_memtime();
+  }
+}
+__device__ __forceinline__ void stamp(const KP& p, int slot) {
+  if ((p.dbg & 64) && threadIdx.x == 0) {
+    const int wg = blockIdx.x + gridDim.x * blockIdx.z;
+    if (wg < kStampWGs) g_stamps[wg * kStampSlots + slot] = __builtin_amdgcn_s_memrealtime();
+  }
+}
 
 // 256 bytes of zeros: DMA source for padded / out-of-range rows
 static __device__ __attribute__((aligned(256))) const unsigned int g_zero_page[64] = {0};
@@ -42,9 +61,114 @@ __device__ __forceinline__ int swz_chunk(int row, int chunk) {
 
 // ---- epilogue shared by all kernels: lane holds n = nb + i*16 + fq*4 + {0..3} (4 consecutive channels) of output row
 //      mrow[j] (-1: no such row) for accumulator tile (i, j); nb = first column of this wave's TN-wide strip
+// `scratch` (optional): wave-private LDS, >= epilogue_scratch_bytes(TN) bytes, free of pending DMAs and of other waves'
+// fragment reads.  With it (and p.coalesce set by the host: fp16 output, no split-K, N % 8 == 0, 16-byte aligned rows) the
+// wave transposes each 16-row block of fp32 results through LDS so that every lane then moves 8 consecutive channels:
+// 16-byte residual loads and 16-byte stores in runs of TN*2 contiguous bytes per row, instead of 8-byte pieces in 32-byte
+// runs (measured: the 8-byte epilogue took ~4 us of a 24 us conv).  Same arithmetic, same single rounding.
+constexpr int epilogue_scratch_bytes(int tn) { return 16 * (tn * 4 + 16); }
+
+// one 16-row block of the coalesced epilogue, flags resolved at compile time (a scalar branch per flag per tile cost more
+// than the arithmetic: ~60 taken branches per wave)
+template <int NI, int TN, bool B2, int ACT>
+__device__ __forceinline__ void stage_block(const KP& p, const f32x4 (&accj)[NI], const f32x4 (&bias)[NI], int m, int nb, int fq,
+                                            int frow, char* scratch) {
+  constexpr int ROWB = TN * 4 + 16;
+  const float* b2p = nullptr;
+  if (B2) b2p = p.bias2 + (size_t)(m >= 0 ? m / p.HoWo : 0) * p.ld_bias2 + nb + fq * 4;
+  f32x4 b2[NI];
+  if (B2) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      b2[i] = (nb + i * 16 + fq * 4 < p.N) ? *reinterpret_cast<const f32x4*>(b2p + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    f32x4 v = accj[i] + bias[i];
+    if (B2) v += b2[i];
+    if (ACT == 1) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
+    } else if (ACT == 2) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[t] = quick_gelu_f(v[t]);
+    }
+    v *= p.scale;
+    *reinterpret_cast<f32x4*>(scratch + frow * ROWB + (i * 16 + fq * 4) * 4) = v;
+  }
+}
+
 template <int NI, int MI, int TN>
 __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI], const int (&mrow)[MI], int nb, int fq, int z,
-                                              const f32x4 (&bpre)[NI], bool use_bpre) {
+                                              const f32x4 (&bpre)[NI], bool use_bpre, char* scratch = nullptr) {
+  if (scratch && p.coalesce) {
+    constexpr int ROWB = TN * 4 + 16;            // odd multiple of 16 bytes: the 16 rows of a block start in different banks
+    constexpr int G = TN / 8;                    // 8-channel groups per row
+    constexpr int PASSES = (16 * G + 63) / 64;
+    const int lane = threadIdx.x & 63, frow = lane & 15;
+    // per-channel bias of this lane's tiles (zeros when absent), second-phase coordinates: the same for every block
+    f32x4 bias[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int n = nb + i * 16 + fq * 4;
+      bias[i] = use_bpre ? bpre[i] : ((p.bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    int rr[PASSES], nn[PASSES];
+    bool live[PASSES];
+#pragma unroll
+    for (int t = 0; t < PASSES; ++t) {
+      const int id = t * 64 + lane;
+      rr[t] = id / G;
+      nn[t] = nb + (id - rr[t] * G) * 8;
+      live[t] = id < 16 * G && nn[t] < p.N;
+    }
+    const int mode = (p.bias2 ? 3 : 0) + p.act;   // act is 0..2 here (3 = GEGLU never takes this path)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      const int m = mrow[j];
+      // residual loads of this block first: they are independent of the staging
+      int mm[PASSES];
+      f16x8 resv[PASSES];
+#pragma unroll
+      for (int t = 0; t < PASSES; ++t) {
+        const int msrc = __shfl(m, rr[t] & 15, 64);          // lane r (fq == 0) holds the row index of block row r
+        mm[t] = live[t] ? msrc : -1;
+        resv[t] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+      if (p.res) {
+#pragma unroll
+        for (int t = 0; t < PASSES; ++t)
+          if (mm[t] >= 0) resv[t] = *reinterpret_cast<const f16x8*>(p.res + (size_t)mm[t] * p.ldres + nn[t]);
+      }
+      f32x4 accj[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) accj[i] = acc[i][j];
+      switch (mode) {
+        case 0: stage_block<NI, TN, false, 0>(p, accj, bias, m, nb, fq, frow, scratch); break;
+        case 1: stage_block<NI, TN, false, 1>(p, accj, bias, m, nb, fq, frow, scratch); break;
+        case 2: stage_block<NI, TN, false, 2>(p, accj, bias, m, nb, fq, frow, scratch); break;
+        case 3: stage_block<NI, TN, true, 0>(p, accj, bias, m, nb, fq, frow, scratch); break;
+        case 4: stage_block<NI, TN, true, 1>(p, accj, bias, m, nb, fq, frow, scratch); break;
+        default: stage_block<NI, TN, true, 2>(p, accj, bias, m, nb, fq, frow, scratch); break;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < PASSES; ++t) {
+        if (mm[t] < 0) continue;
+        const char* src = scratch + rr[t] * ROWB + (nn[t] - nb) * 4;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 16);
+        f16x8 o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          o[u] = (f16)(lo[u] + (float)resv[t][u]);
+          o[4 + u] = (f16)(hi[u] + (float)resv[t][4 + u]);
+        }
+        *reinterpret_cast<f16x8*>(p.y + (size_t)mm[t] * p.ldy + nn[t]) = o;
+      }
+      __builtin_amdgcn_wave_barrier();        // the next block overwrites the scratch rows
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
     const int m = mrow[j];
@@ -115,14 +239,14 @@ __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI],
 // implicit-GEMM tiles: accumulator tile (i, j) of wave (wm, wn) is output row m0 + wm*TM + j*16 + frow
 template <int NI, int MI, int TM, int TN>
 __device__ __forceinline__ void epilogue(const KP& p, f32x4 (&acc)[NI][MI], int m0, int n0, int wm, int wn, int frow, int fq, int z,
-                                         const f32x4 (&bpre)[NI], bool use_bpre) {
+                                         const f32x4 (&bpre)[NI], bool use_bpre, char* scratch = nullptr) {
   int mrow[MI];
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
     const int m = m0 + wm * TM + j * 16 + frow;
     mrow[j] = m < p.M ? m : -1;
   }
-  epilogue_rows<NI, MI, TN>(p, acc, mrow, n0 + wn * TN, fq, z, bpre, use_bpre);
+  epilogue_rows<NI, MI, TN>(p, acc, mrow, n0 + wn * TN, fq, z, bpre, use_bpre, scratch);
 }
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (observed, speed only), so give each

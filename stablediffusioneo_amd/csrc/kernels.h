@@ -35,6 +35,9 @@ struct ConvGemm {
   int force_splitk = 0;
 };
 int conv_gemm(const ConvGemm& p, hipStream_t stream);
+// measurement only: phase stamps of the last launch of an implicit-GEMM / halo kernel (SDEO_DBG_GEMM bit 6), see conv_inl.h
+int conv_gemm_read_stamps(unsigned long long* out, int n);
+int conv_halo_read_stamps(unsigned long long* out, int n);
 size_t conv_gemm_workspace_bytes(const ConvGemm& p);
 // name of the kernel instantiation the launcher will pick (for profiles; matches the rocprof kernel name's template args)
 const char* conv_gemm_kernel_name(const ConvGemm& p);

@@ -139,7 +139,7 @@ def test_conv2d_epilogue(ops):
     assert_close(y.permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3, what="conv epilogue")
 
 
-DMA_TILES = [0, 1, 2, 5, 6, 7, 8, 9]     # kTiles indices of conv_gemm_dma_kernel<BM,BN,STAGES> in csrc/conv_gemm.hip
+DMA_TILES = [0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 19, 20, 21]     # kTiles indices of conv_gemm_dma_kernel<BM,BN,STAGES> in csrc/conv_gemm.hip
 
 
 @pytest.mark.parametrize("tile", DMA_TILES)
@@ -164,7 +164,8 @@ def test_conv2d_every_dma_tile(ops, tile, sk):
         lib.sdeo_debug_force_gemm_plan(C.c_int(-1), C.c_int(0))
 
 
-HALO_TILES = {13: (8, 16, 80), 14: (8, 16, 160), 15: (8, 8, 80), 16: (8, 8, 160), 17: (8, 16, 64), 18: (8, 16, 128)}   # kTiles index -> (PH, PW, BN)
+HALO_TILES = {13: (8, 16, 80, 4), 14: (8, 16, 160, 4), 15: (8, 8, 80, 4), 16: (8, 8, 160, 4), 17: (8, 16, 64, 4), 18: (8, 16, 128, 4),
+              22: (8, 16, 80, 8), 23: (8, 16, 160, 8), 24: (8, 16, 64, 8), 25: (8, 16, 128, 8)}   # kTiles index -> (PH, PW, BN, MFMA waves)
 
 
 @pytest.mark.parametrize("tile", sorted(HALO_TILES))
@@ -177,13 +178,13 @@ def test_conv2d_every_halo_tile(ops, tile, sk):
     from stablediffusioneo_amd import _lib
     lib = _lib.load()
     lib.sdeo_debug_conv2d_kernel_name.restype = C.c_char_p
-    ph, pw, bn = HALO_TILES[tile]
+    ph, pw, bn, nmw = HALO_TILES[tile]
     try:
         lib.sdeo_debug_force_gemm_plan(C.c_int(tile), C.c_int(sk))
         for (n, cin, h, w, cout) in [(2, 320, 2 * ph, 2 * pw, 320), (1, 64, ph, pw, 72), (2, 128, 3 * ph, pw, 164), (1, 192, ph, 3 * pw, 640)]:
             name = lib.sdeo_debug_conv2d_kernel_name(C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(cin), C.c_int(cout), C.c_int(3),
                                                      C.c_int(1), C.c_int(0)).decode()
-            assert name == f"conv3x3_halo_kernel<{ph},{pw},{bn}>", name
+            assert name == f"conv3x3_halo_kernel<{ph},{pw},{bn},{nmw}>", name
             x = h16(randn((n, cin, h, w), 240 + cin))
             wt = h16(randn((cout, cin, 3, 3), 241) * (1.0 / (cin * 9)) ** 0.5)
             bias = 0.1 * randn((cout,), 242)
