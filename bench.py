@@ -11,8 +11,9 @@ resident in HBM.  Images are sharded over ranks by image index (no data-path col
 gathered once with RCCL inside the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline     -- the dominant kernel (by device time) of one profiled image: algorithmic FLOPs of its launches /
-                  their summed HIP-event durations, against the dense fp16 MFMA peak (2.5 PFLOP/s).
+  roofline     -- the dominant (kernel, problem shape) pair by device time of one profiled image: algorithmic FLOPs of its
+                  launches / their summed HIP-event durations, against the dense fp16 MFMA peak (2.5 PFLOP/s); `traffic` is
+                  the committed rocprofv3 --pmc measurement of the same pair (profiles/r01_traffic.json).
   cpu_baseline -- the oracle (oracle/sd_oracle.py = fp32 PyTorch restatement of the reference path, "port") timed
                   on this host's cores on a bounded sample (N=1 only).
 """
@@ -23,6 +24,8 @@ import json
 import os
 import sys
 import time
+
+os.environ.setdefault("SDEO_PROFILE_DETAIL", "1")     # in-library profiler keys = "kernel | problem shape"
 
 import torch
 
@@ -160,10 +163,15 @@ def main():
         one_image(10_000, timed=False)
         prof = rt.profile_end()
         dh.USE_GRAPH = True
+        # records are per (kernel, problem shape); the roofline object describes the pair with the largest share of device time
         mm = [k for k in prof if k["flops"] > 0]
         dom = max(mm, key=lambda k: k["total_ms"])
         tot_ms = sum(k["total_ms"] for k in prof)
         ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+        by_kernel = {}
+        for k in prof:
+            name = k["kernel"].split(" | ")[0]
+            by_kernel[name] = by_kernel.get(name, 0.0) + k["total_ms"]
         traffic, tnote = None, None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath):          # PMC numbers cannot be taken inside this process: committed rocprofv3 --pmc result
@@ -175,8 +183,9 @@ def main():
                 "kernel": dom["kernel"],
                 "launches_per_image": dom["launches"], "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2),
                 "share_of_device_time": round(dom["total_ms"] / tot_ms, 3),
-                "by_kernel_ms_per_image": {k["kernel"]: round(k["total_ms"], 2) for k in
-                                           sorted(prof, key=lambda k: -k["total_ms"])}}
+                "top_shapes_ms_per_image": {k["kernel"]: round(k["total_ms"], 2) for k in
+                                            sorted(prof, key=lambda k: -k["total_ms"])[:8]},
+                "by_kernel_ms_per_image": {n: round(v, 2) for n, v in sorted(by_kernel.items(), key=lambda kv: -kv[1])}}
 
     if rank == 0:
         images = world * a.steps
