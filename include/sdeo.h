@@ -112,6 +112,16 @@ int sdeo_cfg_ddim_step(float* x_prev, float* pred_x0, const float* x, const floa
                        const float* noise, float cfg_scale, float a_t, float a_prev, float sigma_t,
                        float sqrt_one_minus_at, int64_t n, void* stream);
 
+/* Canny edge map: replaces `cv2.Canny(img, low_threshold, high_threshold)` of annotator/canny/__init__.py:4-6
+ * (aperture 3, L1 gradient magnitude; called at canny2image_torch.py:33 on the HWC3 uint8 image) and the control preparation of
+ * canny2image_torch.py:34-38.  img_hwc: device uint8 [h][w][c], c in 1..4.  edges (optional): device uint8 [h][w], 0 / 255.
+ * control_chw (optional): device fp32 [3][h][w] = edges / 255 on three identical channels (HWC3 + /255 + HWC->CHW).
+ * workspace: >= sdeo_canny_workspace_bytes(h, w) bytes of device memory.  Unlike the other entry points this one
+ * synchronises `stream` (hysteresis is iterated to a fixed point) and is not graph-capturable. */
+size_t sdeo_canny_workspace_bytes(int h, int w);
+int sdeo_canny_u8(const uint8_t* img_hwc, int h, int w, int c, float low_threshold, float high_threshold, uint8_t* edges,
+                  float* control_chw, void* workspace, size_t workspace_bytes, void* stream);
+
 /* layout helpers at the NCHW boundary */
 int sdeo_nchw_f32_to_nhwc_f16(void* y, int ldy, const float* x, int n, int c, int hw, void* stream);
 int sdeo_nhwc_f16_to_nchw_f32(float* y, const void* x, int ldx, int n, int c, int hw, float scale, void* stream);

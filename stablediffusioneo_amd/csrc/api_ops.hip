@@ -70,6 +70,13 @@ size_t sdeo_conv2d_workspace_bytes(int n, int h, int w, int cin, int cout, int k
   return conv_gemm_workspace_bytes(p);
 }
 
+size_t sdeo_canny_workspace_bytes(int h, int w) { return canny_workspace_bytes(h, w); }
+
+int sdeo_canny_u8(const uint8_t* img_hwc, int h, int w, int c, float low_threshold, float high_threshold, uint8_t* edges,
+                  float* control_chw, void* workspace, size_t workspace_bytes, void* stream) {
+  return canny_u8(img_hwc, h, w, c, low_threshold, high_threshold, edges, control_chw, workspace, workspace_bytes, S(stream));
+}
+
 int sdeo_debug_read_stamps(int which, unsigned long long* out, int n) {
   return which ? conv_halo_read_stamps(out, n) : conv_gemm_read_stamps(out, n);
 }

@@ -103,6 +103,11 @@ int geglu_interleave_f32(float* y, const float* x, int H, hipStream_t stream);
 // CLIP text embeddings: out[(b*T + t)][0:W] = tok_emb[ids[b*T + t]][0:W] + pos_emb[t][0:W]   (ids are clamped to [0, vocab))
 int embed_tokens(f16* out, const int32_t* ids, const f16* tok_emb, const f16* pos_emb, int B, int T, int W, int vocab,
                  hipStream_t stream);
+// cv2.Canny(img, low, high) (aperture 3, L1 magnitude) on an HWC uint8 image of 1..4 channels -> edges [H][W] uint8 0 / 255 and / or
+// control [3][H][W] fp32 = edges / 255.  Synchronises `stream` (hysteresis runs to a fixed point).  csrc/canny.hip
+size_t canny_workspace_bytes(int H, int W);
+int canny_u8(const uint8_t* img, int H, int W, int C, float low_threshold, float high_threshold, uint8_t* edges, float* control,
+             void* workspace, size_t workspace_bytes, hipStream_t stream);
 // classifier-free guidance + DDIM update on NCHW fp32 latents (ddim_hacked.py:192,208-231)
 int cfg_ddim_step(float* x_prev, float* pred_x0, const float* x, const float* eps_c, const float* eps_u, const float* noise,
                   float cfg_scale, float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at, int64_t n,

@@ -1,0 +1,96 @@
+"""GPU parity of the Canny path (csrc/canny.hip through `sdeo_canny_u8`): BIT-EXACT against
+oracle/canny_oracle.py (integer arithmetic).  The oracle itself is parity-unpinned against OpenCV (tests/test_canny_oracle.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.common import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def det():
+    from stablediffusioneo_amd.annotator.canny import CannyDetector
+    return CannyDetector()
+
+
+def test_reference_picture(det):
+    from oracle import canny_oracle as O
+    g = np.load(os.path.join(GOLDEN, "canny.npz"))
+    img = g["image"]
+    e = det(img, 100, 200)
+    assert isinstance(e, np.ndarray) and e.dtype == np.uint8 and e.shape == img.shape[:2]
+    np.testing.assert_array_equal(e, O.canny(img, 100, 200))
+    c = det.control_hint(img, 100, 200)
+    assert c.is_cuda and c.shape == (3,) + img.shape[:2]
+    np.testing.assert_array_equal(c.cpu().numpy(), O.control_from_edges(e, 1)[0])
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 3), (1, 37, 3), (41, 1, 1), (33, 65, 3), (64, 64, 1), (100, 130, 4), (256, 384, 3), (512, 512, 3)])
+@pytest.mark.parametrize("th", [(100, 200), (30.7, 60.2), (250, 20), (0, 0), (2000, 3000)])
+def test_random_images(det, shape, th):
+    """noise (dense candidates, every sector of the direction test), blurred noise (long chains), ragged sizes, 1 / 3 / 4 channels,
+    swapped / fractional / degenerate thresholds"""
+    from oracle import canny_oracle as O
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    if min(shape[:2]) >= 16:
+        from scipy import ndimage
+        img = ndimage.uniform_filter(img.astype(np.float32), size=(5, 5, 1)).astype(np.uint8)
+        img = ((img.astype(np.int32) - 96) * 4).clip(0, 255).astype(np.uint8)
+    np.testing.assert_array_equal(det(img, *th), O.canny(img, *th))
+
+
+def test_hysteresis_across_many_tiles(det):
+    """a one-pixel-wide weak spiral that is an edge only because ONE end is strong: the 32x32-tile kernel has to be relaunched once
+    per tile boundary the chain crosses"""
+    from oracle import canny_oracle as O
+    H = W = 200
+    img = np.zeros((H, W), np.uint8)
+    y, x, dy, dx, run = 4, 4, 0, 1, W - 8
+    path = []
+    while run > 8:
+        for _ in range(run):
+            path.append((y, x))
+            y, x = y + dy, x + dx
+        dy, dx = dx, -dy
+        run -= 6
+    for (py, px) in path:
+        img[py, px] = 40                 # weak ridge: magnitude between the thresholds
+    for (py, px) in path[:3]:
+        img[py, px] = 255                # strong seed at one end
+    ref = O.canny(img, 60, 400)
+    got = det(img, 60, 400)
+    np.testing.assert_array_equal(got, ref)
+    assert ref.sum() > 255 * 500         # the chain really is long, and kept
+
+
+def test_tensor_in_tensor_out_and_errors(det):
+    from stablediffusioneo_amd._lib import SdeoError
+    img = torch.randint(0, 256, (48, 80, 3), dtype=torch.uint8)
+    e = det(img.cuda(), 50, 150)
+    assert e.is_cuda and e.dtype == torch.uint8
+    np.testing.assert_array_equal(e.cpu().numpy(), det(img.numpy(), 50, 150))
+    with pytest.raises(SdeoError):
+        det(np.zeros((8, 8, 3), np.float32), 1, 2)
+    with pytest.raises(SdeoError):
+        det(np.zeros((8, 8, 5), np.uint8), 1, 2)
+
+
+def test_process_uses_the_hip_detector():
+    """hackathon.process with its default detector == the same pipeline fed the oracle's edge map"""
+    from oracle import canny_oracle as O
+    from stablediffusioneo_amd import canny2image as c2i, spec as S
+    from stablediffusioneo_amd.annotator.canny import CannyDetector
+    g = np.load(os.path.join(GOLDEN, "canny.npz"))
+    img = g["image"][:64, :64].copy()
+    enc = lambda prompts: c2i.synthetic_text_encoder(prompts, 77, S.UNET_TINY.context_dim)
+    hk = c2i.hackathon().initialize("synthetic:0", config="tiny", text_encoder=enc)
+    assert isinstance(hk.apply_canny, CannyDetector)          # the default detector is the HIP one
+    a = hk.process(img, "a bird", "best quality", "lowres", 1, 64, 2, False, 1.0, 9.0, 7, 0.0, 100, 200)
+    hk.apply_canny = lambda im, lo, hi: O.canny(im, lo, hi)   # the reference-style numpy-in / numpy-out branch
+    b = hk.process(img, "a bird", "best quality", "lowres", 1, 64, 2, False, 1.0, 9.0, 7, 0.0, 100, 200)
+    np.testing.assert_array_equal(a[0], b[0])
