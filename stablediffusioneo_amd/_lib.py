@@ -54,6 +54,10 @@ def load(path: str = LIB_PATH):
     if not os.path.exists(path):
         raise SdeoError(f"{path} not found: build it with `python -m stablediffusioneo_amd.build` "
                         f"(there is no CPU / PyTorch fallback for the HIP path)")
+    # Load order: PyTorch ships its own libamdhip64 / libhsa-runtime64 and libsdeo.so is linked against /opt/rocm's.  Whichever
+    # is loaded first owns the soname; with libsdeo first, torch ends up with two HSA runtimes in the process and every later
+    # HIP call fails with "no ROCm-capable device".  This host uses torch for device memory and streams, so torch goes first.
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     if missing:
