@@ -342,3 +342,19 @@ def ddim_sample(apply_fn, x_T, S, cond, uncond, scale, eta=0.0, schedule=None, n
         inter["x_inter"].append(img)
         inter["pred_x0"].append(pred_x0)
     return img, inter
+
+
+def ddim_encode(apply_fn, x0, S, t_enc, cond):
+    """DDIM inversion without guidance, `cldm/ddim_hacked.py:233-279` (DDIM timesteps, `use_original_steps=False`):
+    x_next = sqrt(a_next / a) x + sqrt(a_next) (sqrt(1/a_next - 1) - sqrt(1/a - 1)) eps(x, t_i)  for i < t_enc, with
+    a_next = ddim_alphas[i], a = ddim_alphas_prev[i]."""
+    ac = register_schedule()["alphas_cumprod"]
+    ts = make_ddim_timesteps(S)
+    _, alphas, alphas_prev = make_ddim_sampling_parameters(ac, ts, 0.0)
+    x = x0.clone()
+    for i in range(t_enc):
+        t = torch.full((x0.shape[0],), int(ts[i]), dtype=torch.long)
+        e = apply_fn(x, t, cond)
+        a_next, a = float(alphas[i]), float(alphas_prev[i])
+        x = (a_next / a) ** 0.5 * x + a_next ** 0.5 * ((1 / a_next - 1) ** 0.5 - (1 / a - 1) ** 0.5) * e
+    return x

@@ -80,7 +80,10 @@ TUNED_PLANS = os.path.join(HERE, "tuned_plans_gfx950.json")
 def load_tuned_plans(lib, path: str = TUNED_PLANS) -> int:
     """Push the committed (tile, split-K) table into the library; returns the number of entries."""
     import json
-    if not os.path.exists(path) or os.environ.get("SDEO_TUNED_PLANS", "1") == "0":   # 0: re-measure everything (tools/tune_plans.py)
+    env = os.environ.get("SDEO_TUNED_PLANS", "1")      # 0: re-measure everything (tools/tune_plans.py); a path: that table instead
+    if env not in ("0", "1"):
+        path = env
+    if not os.path.exists(path) or env == "0":
         return 0
     rows = json.load(open(path))
     for r in rows:

@@ -89,6 +89,8 @@ class ControlLDM:
         self.betas = to_t(betas)
         self.alphas_cumprod = to_t(ac)
         self.alphas_cumprod_prev = to_t(np.append(1.0, ac[:-1]))
+        self.sqrt_alphas_cumprod = to_t(np.sqrt(ac))
+        self.sqrt_one_minus_alphas_cumprod = to_t(np.sqrt(1.0 - ac))
 
     # -- nn.Module-ish conveniences the pipeline scripts call
     def cuda(self):
@@ -122,6 +124,15 @@ class ControlLDM:
         return self.get_learned_conditioning([""] * N)
 
     # -- the hot call
+    def q_sample(self, x_start, t, noise=None):
+        """Forward diffusion x_t = sqrt(abar_t) x_0 + sqrt(1 - abar_t) eps, called by the sampler's mask / x0 branch
+        (`cldm/ddim_hacked.py:154-157`).  `LatentDiffusion.q_sample` itself is absent from the reference tree: upstream
+        SD-v1 semantics, parity unpinned."""
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        ext = lambda a: a.to(x_start.device)[t].reshape(-1, *([1] * (x_start.dim() - 1)))
+        return ext(self.sqrt_alphas_cumprod) * x_start + ext(self.sqrt_one_minus_alphas_cumprod) * noise
+
     def apply_model(self, x_noisy, t, cond, *args, flags: int = 0, out=None, **kwargs):
         """`cldm/cldm.py:328-341`."""
         assert isinstance(cond, dict)

@@ -264,6 +264,48 @@ class DDIMSampler(object):
         return ext(sqrt_ac) * x0 + ext(sqrt_1m) * noise
 
     @torch.no_grad()
+    def encode(self, x0, c, t_enc, use_original_steps=False, return_intermediates=None, unconditional_guidance_scale=1.0,
+               unconditional_conditioning=None, callback=None):
+        """DDIM inversion, `cldm/ddim_hacked.py:233-279`: t_enc deterministic steps from x0 towards noise.  (With guidance the
+        reference concatenates the two conditionings as tensors, `:257-259`, which only works for tensor conditionings; here the
+        pair goes through the same fused cond / uncond pass as sampling.)"""
+        timesteps = np.arange(self.ddpm_num_timesteps) if use_original_steps else self.ddim_timesteps
+        assert t_enc <= timesteps.shape[0]
+        num_steps = t_enc
+        if use_original_steps:
+            alphas_next = self.model.alphas_cumprod[:num_steps].double().cpu().numpy()
+            alphas = self.model.alphas_cumprod_prev[:num_steps].double().cpu().numpy()
+        else:
+            alphas_next = np.asarray(self.ddim_alphas[:num_steps], dtype=np.float64)
+            alphas = np.asarray(self.ddim_alphas_prev[:num_steps], dtype=np.float64)
+        x_next = x0.to(device=self.model.device, dtype=torch.float32)
+        intermediates, inter_steps = [], []
+        self._cache_key = None
+        for i in range(num_steps):
+            t = torch.full((x0.shape[0],), int(timesteps[i]), device=self.model.device, dtype=torch.long)
+            if unconditional_guidance_scale == 1.:
+                noise_pred = self.model.apply_model(x_next, t, c)
+            else:
+                assert unconditional_conditioning is not None
+                e_c, e_u = self._eps_pair(x_next, c, t, unconditional_conditioning, unconditional_guidance_scale)
+                noise_pred = e_u + unconditional_guidance_scale * (e_c - e_u)
+            xt_weighted = float(np.sqrt(alphas_next[i] / alphas[i])) * x_next
+            weighted_noise_pred = float(np.sqrt(alphas_next[i]) * (np.sqrt(1 / alphas_next[i] - 1) - np.sqrt(1 / alphas[i] - 1))) * noise_pred
+            x_next = xt_weighted + weighted_noise_pred
+            if return_intermediates and i % (num_steps // return_intermediates) == 0 and i < num_steps - 1:
+                intermediates.append(x_next)
+                inter_steps.append(i)
+            elif return_intermediates and i >= num_steps - 2:
+                intermediates.append(x_next)
+                inter_steps.append(i)
+            if callback:
+                callback(i)
+        out = {"x_encoded": x_next, "intermediate_steps": inter_steps}
+        if return_intermediates:
+            out.update({"intermediates": intermediates})
+        return x_next, out
+
+    @torch.no_grad()
     def decode(self, x_latent, cond, t_start, unconditional_guidance_scale=1.0, unconditional_conditioning=None,
                use_original_steps=False, callback=None):
         """`cldm/ddim_hacked.py:297-317`."""

@@ -170,6 +170,61 @@ def test_hint_and_context_are_computed_once_per_image(tiny_model):
     assert counts[2] - counts[1] == 2 * per_step, counts
 
 
+def test_ddim_encode_vs_oracle(tiny_model):
+    """DDIMSampler.encode (DDIM inversion, `cldm/ddim_hacked.py:233-279`) against the oracle's restatement; tolerance as for
+    sampling: a trajectory feeds fp16 network error back through the steps"""
+    from stablediffusioneo_amd.cldm.ddim_hacked import DDIMSampler
+    O, S, su, sc, sv, up, cp, hc, levels = oracle_bits()
+    m = tiny_model
+    m.control_scales = [1.0] * 13
+    dev = m.device
+    x0, ctx, hint = make_inputs(1, 8, 8, ctx_dim=m.rt.ucfg.context_dim)
+    s = DDIMSampler(m)
+    s.make_schedule(10, ddim_eta=0.0, verbose=False)
+    cond = {"c_concat": [hint.to(dev)], "c_crossattn": [ctx.to(dev)]}
+    enc, out = s.encode(x0.to(dev), cond, 4, return_intermediates=2)
+    assert out["x_encoded"] is enc and len(out["intermediates"]) >= 2
+    with torch.no_grad():
+        ref = O.ddim_encode(lambda x, t, c: O.apply_model(su, sc, up, cp, hc, x, t, c, hint, [1.0] * 13), x0, 10, 4, ctx)
+    e = rel(enc, ref)
+    print(f"[parity] DDIM encode, 4 of 10 steps: max|err|/scale = {e:.3e}")
+    assert e < 3e-2
+
+
+def test_q_sample_and_mask_branch(tiny_model):
+    """q_sample (upstream LatentDiffusion semantics, parity unpinned: SURVEY A20) and the sampler's mask / x0 blending
+    (`cldm/ddim_hacked.py:154-157`): with mask == 1 everywhere the result of every step is overwritten by q_sample(x0, t), so the
+    final latent is one DDIM step away from q_sample(x0, t_last) whatever x_T was"""
+    from stablediffusioneo_amd.cldm.ddim_hacked import DDIMSampler
+    m = tiny_model
+    m.control_scales = [1.0] * 13
+    dev = m.device
+    x0, ctx, hint = make_inputs(1, 8, 8, ctx_dim=m.rt.ucfg.context_dim)
+    noise = randn((1, 4, 8, 8), 77).to(dev)
+    t = torch.tensor([601], device=dev)
+    got = m.q_sample(x0.to(dev), t, noise)
+    ac = float(m.alphas_cumprod[601])
+    np.testing.assert_allclose(got.cpu().numpy(), (ac ** 0.5 * x0 + (1 - ac) ** 0.5 * noise.cpu()).numpy(), rtol=1e-5, atol=1e-6)
+    cond = {"c_concat": [hint.to(dev)], "c_crossattn": [ctx.to(dev)]}
+    s = DDIMSampler(m)
+    calls = []
+    orig = m.q_sample
+    m.q_sample = lambda x, ts, noise=None: (calls.append(int(ts[0])), ac_mix(m, x, ts))[1]
+    try:
+        mask = torch.ones((1, 1, 8, 8), device=dev)
+        a, _ = s.sample(4, 1, (4, 8, 8), cond, verbose=False, eta=0.0, x_T=randn((1, 4, 8, 8), 5), mask=mask, x0=x0.to(dev))
+        b, _ = s.sample(4, 1, (4, 8, 8), cond, verbose=False, eta=0.0, x_T=randn((1, 4, 8, 8), 6), mask=mask, x0=x0.to(dev))
+    finally:
+        m.q_sample = orig
+    assert calls[:4] == [751, 501, 251, 1]             # one q_sample per step, at that step's timestep
+    assert torch.equal(a, b)                           # x_T is fully masked out
+
+
+def ac_mix(m, x, ts):
+    """deterministic stand-in for q_sample's noise draw: eps = 0"""
+    return m.sqrt_alphas_cumprod.to(x.device)[ts].reshape(-1, 1, 1, 1) * x
+
+
 def test_engine_surface(tiny_model):
     """Engine(...).load().activate().allocate_buffers().infer() with the reference's names and positions,
     eager and graph-captured."""
