@@ -10,7 +10,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsdeo.so")
+LIB_PATH = os.environ.get("SDEO_LIB") or os.path.join(HERE, "libsdeo.so")     # SDEO_LIB: A/B of two builds on one device
 HEADER = os.path.join(os.path.dirname(HERE), "include", "sdeo.h")
 
 _lib = None

@@ -52,6 +52,11 @@ void attention_kernel(const AP p) {
   constexpr int KCH = D16 * 2;                               // 16-byte chunk slots per K row
   constexpr int KITEMS = 64 * KCH, KPASS = (KITEMS + NT - 1) / NT;
   constexpr int VITEMS = DT * 32 * 8, VPASS = (VITEMS + NT - 1) / NT;
+  // Row sum for free (odd D16 only): P V pads d to DT*32 = 16 (D16 + 1) rows of O^T, QK^T only to 16 D16, so row R1 = 16 D16 of
+  // the V^T tile is never a real channel.  Filled with ones, the MFMA leaves sum_k P[k][q] in that row of O^T (register 8 of the
+  // last tile, lanes 0..31): no per-score add, no cross-half exchange per tile, and the running sum is rescaled with O.
+  constexpr bool ONES = (D16 % 2) == 1;
+  constexpr int R1 = 16 * D16;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -97,6 +102,7 @@ void attention_kernel(const AP p) {
   const f16* kptr[KPASS];
   const f16* vptr[VPASS];
   int krow[KPASS], kdst[KPASS], vkey[VPASS], vdst[VPASS];
+  bool vones[VPASS];
 #pragma unroll
   for (int i = 0; i < KPASS; ++i) {
     const int it = tid + i * NT;
@@ -112,6 +118,7 @@ void attention_kernel(const AP p) {
     const int row = it >> 3, c = it & 7;
     const bool use = it < VITEMS && row < d;
     vkey[i] = use ? c * 8 : (1 << 30);
+    vones[i] = ONES && it < VITEMS && row == R1;
     vptr[i] = vbase + (size_t)row * p.ldvt + c * 8;
     vdst[i] = it < VITEMS ? row * VROW + c * 16 : -1;
   }
@@ -126,7 +133,7 @@ void attention_kernel(const AP p) {
 #pragma unroll
     for (int i = 0; i < VPASS; ++i) {
       const int key = key0 + vkey[i];
-      f16x8 v = zero8;
+      f16x8 v = vones[i] ? f16x8{(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f} : zero8;
       if (key < p.Tk) {
         v = *reinterpret_cast<const f16x8*>(vptr[i]);
         if (key + 8 > p.Tk) {  // partially valid chunk: zero the keys >= Tk (P is 0 there, V must be finite)
@@ -211,9 +218,9 @@ void attention_kernel(const AP p) {
       for (int r = 0; r < 16; ++r) {
         const float pv = __builtin_amdgcn_exp2f(fmaf(s[ki][r], p.scale_log2, -m_use));
         s[ki][r] = pv;
-        rs += pv;
+        if (!ONES) rs += pv;
       }
-    rs += __shfl_xor(rs, 32, 64);
+    if (!ONES) rs += __shfl_xor(rs, 32, 64);
     if (__any(m_new > m_run)) {      // wave-uniform: after the first few tiles the running max rarely moves
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
@@ -275,6 +282,7 @@ void attention_kernel(const AP p) {
       for (int r = 0; r < 16; ++r) o[t][r] = o[t][r] * a0 + mg[(2 + t * 16 + r) * 64] * a1;
   }
 
+  if constexpr (ONES) l_run = __shfl(o[DT - 1][8], lq, 64);     // row R1 of O^T: register 8 of the last tile in lanes 0..31
   // ---- normalise and store: o[t][4g..4g+3] = O[qrow][t*32 + 8g + 4lh + 0..3]
   if (qvalid) {
     const float inv = 1.0f / l_run;
