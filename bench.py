@@ -51,38 +51,65 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--config", default="sd15", choices=["sd15", "tiny"])
+    ap.add_argument("--fast-weights", action="store_true",
+                    help="draw the synthetic weights with the device generator (seconds faster to start; NOT the parity-tested weights, "
+                         "so the reference-golden check of the output is skipped)")
+    ap.add_argument("--dump-profile", default="", help="write the full per-(kernel, shape) table of the profiled image to this JSON file")
     return ap.parse_args()
 
 
 def cpu_baseline(res, ddim_steps, scale):
-    """Oracle ("port" of the reference PyTorch path) on the host cores, bounded sample: ONE apply_model pass (ControlNet +
-    ControlledUnet, N=1, fp32, synthetic weights) at the benchmark resolution.  The reference runs two such passes per
-    DDIM step (`cldm/ddim_hacked.py:190-191`), so images/s = 1 / (ddim_steps * 2 * t_pass); VAE decode not included."""
+    """Oracle ("port" of the reference PyTorch path, fp32) on the host cores, bounded samples, synthetic weights:
+      (a) the benchmark configuration: ONE apply_model pass (ControlNet + ControlledUnet, N=1) and ONE VAE decode at `res`;
+          the reference runs two such passes per DDIM step (`cldm/ddim_hacked.py:190-191`), so
+          images/s = 1 / (ddim_steps * 2 * t_pass + t_vae)  -- this is `value`;
+      (b) BASELINE configs[0] in full (`canny2image_torch.py` shape: 256x256, 5 DDIM steps, CFG, VAE decode), measured, not
+          extrapolated -- reported under `config1`."""
     from oracle import sd_oracle as O
-    from tests.common import make_inputs
+    from tests.common import X_T_SEED, make_hint, make_inputs, randn
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, int(os.environ.get("SDEO_CPU_CORES", "16"))))   # the GPU box grants 16 cores per GPU
     torch.set_num_threads(cores)
-    u = S.UNET_SD15
+    u, v = S.UNET_SD15, S.VAE_SD15
     print(f"[bench] cpu_baseline: generating synthetic fp32 weights on {cores} host threads ...", file=sys.stderr, flush=True)
     su = S.synth_state_dict(S.param_spec_unet(u), 0, S.NS_UNET)
     sc = S.synth_state_dict(S.param_spec_controlnet(u), 0, S.NS_CONTROL)
-    up, cp, hc = S.unet_plan(u), S.unet_plan(u, False), S.hint_block_convs(u)
+    sv = S.synth_state_dict(S.param_spec_vae(v), 0, S.NS_VAE)
+    up, cp, hc, vp = S.unet_plan(u), S.unet_plan(u, False), S.hint_block_convs(u), S.vae_plan(v)[1]
     h = res // 8
     x, ctx, hint = make_inputs(1, h, h)
     t = torch.tensor([951], dtype=torch.long)
-    print("[bench] cpu_baseline: timing one oracle apply_model pass ...", file=sys.stderr, flush=True)
+    print("[bench] cpu_baseline: timing one oracle apply_model pass + one VAE decode ...", file=sys.stderr, flush=True)
     with torch.no_grad():
         t0 = time.perf_counter()
         O.apply_model(su, sc, up, cp, hc, x, t, ctx, hint, [1.0] * 13)
         dt = time.perf_counter() - t0
-    return {"value": 1.0 / (ddim_steps * 2 * dt), "unit": "images/s", "cores": cores, "kind": "port",
-            "seconds_per_apply_model_pass": round(dt, 3),
-            "sample": f"1 apply_model pass (ControlNet + ControlledUnet, N=1) of the fp32 oracle at {res}x{res}; "
-                      f"images/s = 1 / ({ddim_steps} steps x 2 passes x t_pass); VAE decode not included"}
+        t0 = time.perf_counter()
+        O.decode_first_stage(sv, vp, x * v.scale_factor, v.scale_factor)
+        dv = time.perf_counter() - t0
+        # configs[0]: the whole reference pipeline shape at 256x256, 5 DDIM steps
+        print("[bench] cpu_baseline: config 1 (256x256, 5 DDIM steps + VAE) ...", file=sys.stderr, flush=True)
+        h1 = 32
+        hint1 = make_hint(1, 8 * h1, 8 * h1)
+        c1, c2 = randn((1, 77, u.context_dim), 1), randn((1, 77, u.context_dim), 2)
+
+        def apply_fn(xx, tt, cc):
+            return O.apply_model(su, sc, up, cp, hc, xx, tt, cc, hint1, [1.0] * 13)
+
+        t0 = time.perf_counter()
+        z, _ = O.ddim_sample(apply_fn, randn((1, 4, h1, h1), X_T_SEED), 5, c1, c2, scale)
+        img = O.decode_first_stage(sv, vp, z, v.scale_factor)
+        d1 = time.perf_counter() - t0
+        assert bool(torch.isfinite(img).all())
+    return {"value": 1.0 / (ddim_steps * 2 * dt + dv), "unit": "images/s", "cores": cores, "kind": "port",
+            "seconds_per_apply_model_pass": round(dt, 3), "seconds_per_vae_decode": round(dv, 3),
+            "sample": f"1 apply_model pass (ControlNet + ControlledUnet, N=1) + 1 VAE decode of the fp32 oracle at {res}x{res}; "
+                      f"images/s = 1 / ({ddim_steps} steps x 2 passes x t_pass + t_vae)",
+            "config1": {"workload": "BASELINE configs[0]: 256x256, 5 DDIM steps (CFG, 2 passes per step) + VAE decode, fp32 oracle, "
+                                    "measured in full", "seconds_per_image": round(d1, 3), "images_per_s": round(1.0 / d1, 5)}}
 
 
 def main():
@@ -106,7 +133,10 @@ def main():
 
     ucfg, vcfg = (S.UNET_SD15, S.VAE_SD15) if a.config == "sd15" else (S.UNET_TINY, S.VAE_TINY)
     rt = SdeoRuntime(ucfg, vcfg, device=dev)
-    rt.load_synthetic_device(0)
+    if a.fast_weights:
+        rt.load_synthetic_device(0)
+    else:
+        rt.load_synthetic(0)      # the CPU-generator weights of the parity tests and of the reference goldens
     model = ControlLDM(rt)
     sampler = DDIMSampler(model)
     h = w = a.res // 8
@@ -154,6 +184,19 @@ def main():
         elapsed = float(tmax.item())
     loop_ms = sum(e0.elapsed_time(e1) for e0, e1 in loop_ev) / max(len(loop_ev), 1)
     assert torch.isfinite(zloc.float()).all() and int(img.float().std() > 0), "degenerate output"
+    # the benched numerics ARE the parity-tested numerics: image index 0 of the default workload is the trajectory the reference's
+    # own DDIMSampler + ControlLDM.apply_model produced in tests/golden/sd15_full.npz (same weights, x_T, hint, contexts)
+    golden_check = None
+    gpath = os.path.join(ROOT, "tests", "golden", "sd15_full.npz")
+    if (rank == 0 and not a.fast_weights and a.config == "sd15" and (a.res, a.ddim_steps, a.scale) == (512, 20, 9.0)
+            and os.path.exists(gpath)):
+        import numpy as np
+        zref = torch.tensor(np.load(gpath)["traj64.z"])
+        err = (zs[0].float().cpu() - zref).abs()
+        golden_check = {"what": "final latent of image 0 vs the reference DDIMSampler + ControlLDM.apply_model golden (traj64.z)",
+                        "max_abs_err_over_ref_max": round(float(err.max() / zref.abs().max()), 5),
+                        "mean_abs_err_over_ref_max": round(float(err.mean() / zref.abs().max()), 6)}
+        assert golden_check["max_abs_err_over_ref_max"] < 5e-2, f"benchmarked output is off the reference golden: {golden_check}"
 
     roof = None
     if not a.no_roofline and rank == 0:
@@ -168,24 +211,43 @@ def main():
         dom = max(mm, key=lambda k: k["total_ms"])
         tot_ms = sum(k["total_ms"] for k in prof)
         ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-        by_kernel = {}
+        by_kernel, fam = {}, {}
         for k in prof:
             name = k["kernel"].split(" | ")[0]
             by_kernel[name] = by_kernel.get(name, 0.0) + k["total_ms"]
+            f = ("conv_gemm" if name.startswith(("conv_gemm", "conv3x3_halo")) else name)
+            e = fam.setdefault(f, {"ms": 0.0, "flops": 0.0, "launches": 0})
+            e["ms"] += k["total_ms"]; e["flops"] += k["flops"]; e["launches"] += k["launches"]
+        families = {f: {"ms_per_image": round(e["ms"], 2), "launches_per_image": e["launches"],
+                        "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 1) if e["flops"] else None,
+                        "frac_of_mfma_peak": round(e["flops"] / (e["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS_F16, 4) if e["flops"] else None,
+                        "share_of_device_time": round(e["ms"] / tot_ms, 3)} for f, e in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
         traffic, tnote = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):          # PMC numbers cannot be taken inside this process: committed rocprofv3 --pmc result
-            tj = json.load(open(tpath)).get(dom["kernel"])
-            if tj:
-                traffic, tnote = tj["traffic_bytes"], tj["shape"]
+        for tname in ("r02_traffic.json", "r01_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath):          # PMC numbers cannot be taken inside this process: committed rocprofv3 --pmc result
+                tj = json.load(open(tpath)).get(dom["kernel"])
+                if tj:
+                    traffic, tnote = tj["traffic_bytes"], tj["shape"] + f" ({tname})"
+                    break
+        step_counters = None
+        spath = os.path.join(ROOT, "profiles", "r02_step_counters.json")
+        if os.path.exists(spath):
+            step_counters = json.load(open(spath)).get("summary")
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_TFLOPS_F16, 4), "traffic": traffic, "traffic_measured_on": tnote,
                 "kernel": dom["kernel"],
                 "launches_per_image": dom["launches"], "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2),
                 "share_of_device_time": round(dom["total_ms"] / tot_ms, 3),
+                "launches_per_image_all_kernels": sum(k["launches"] for k in prof),
+                "families": families,
+                "whole_step_counters": step_counters,
                 "top_shapes_ms_per_image": {k["kernel"]: round(k["total_ms"], 2) for k in
                                             sorted(prof, key=lambda k: -k["total_ms"])[:8]},
                 "by_kernel_ms_per_image": {n: round(v, 2) for n, v in sorted(by_kernel.items(), key=lambda kv: -kv[1])}}
+        if a.dump_profile:
+            with open(a.dump_profile, "w") as f:
+                json.dump(sorted(prof, key=lambda k: -k["total_ms"]), f, indent=0)
 
     if rank == 0:
         images = world * a.steps
@@ -204,6 +266,8 @@ def main():
                        "guidance_scale": a.scale, "parallelism": f"dp{world} (image index -> rank, RCCL all_gather of final latents)",
                        "weights": "seeded synthetic (no checkpoint in the container)"},
         }
+        if golden_check:
+            out["output_check"] = golden_check
         if roof:
             out["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline and a.config == "sd15":

@@ -42,21 +42,12 @@ typedef struct sdeo_handle_s* sdeo_handle;
 
 const char* sdeo_last_error(void);
 int sdeo_version(void);
-/* tuning hook for tools/tune_gemm.py: force tile config / split-K of the following conv/GEMM launches (-1, 0 = heuristic) */
-void sdeo_debug_force_gemm_plan(int tile, int splitk);
-void sdeo_debug_force_gemm_order(int order); /* -1 heuristic, 0 M-fastest, 1 N-fastest tile order within an XCD */
-/* GEMM plan table: (tile, split-K) per problem shape key {M,N,K,Cin,R,stride,ups,Hi,Wi,B}.  sdeo_configure measures
- * unknown shapes on the device (SDEO_AUTOTUNE=0 disables); known ones come from the table, which
- * stablediffusioneo_amd/tuned_plans_gfx950.json pre-loads so that runs are reproducible and start fast. */
+/* GEMM plan table: (tile, split-K) per problem shape key {M,N,K,Cin,R,stride,ups,Hi,Wi,B}.  Known shapes come from the
+ * table, which stablediffusioneo_amd/tuned_plans_gfx950.json pre-loads so that runs are reproducible and start fast;
+ * unknown shapes use the deterministic heuristic (SDEO_AUTOTUNE=1 measures them on the device at sdeo_configure instead:
+ * a tuning aid, plans and hence fp32 summation orders may then differ from run to run). */
 void sdeo_set_tuned_gemm_plan(const int* key10, int tile, int splitk);
 const char* sdeo_tuned_gemm_plans_json(void);
-/* y = silu(x) on n fp16 elements: launch-floor probe for tools/launch_floor.py */
-/* name of the kernel instantiation sdeo_conv2d_nhwc_f16 would launch for this problem (plan table / forced plan / heuristic) */
-const char* sdeo_debug_conv2d_kernel_name(int n, int h, int w, int cin, int cout, int ksize, int stride, int upsample2x);
-/* measurement only (SDEO_DBG_GEMM bit 6): per-workgroup phase stamps of the last GEMM (which = 0) / halo conv (1) launch,
- * 8 x uint64 per workgroup in 10 ns units */
-int sdeo_debug_read_stamps(int which, unsigned long long* out, int n);
-int sdeo_debug_silu(void* y, const void* x, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------ op-level entry points (used by tests)
 

@@ -77,15 +77,19 @@ def _default_canny():
 class hackathon():
 
     def initialize(self, weights="synthetic:0", config="sd15", apply_canny=None, text_encoder=None):
-        """text_encoder: None = `synthetic_text_encoder` (seeded stand-in contexts); "clip" or "clip:<tokenizer dir>" = the
+        """text_encoder: None = `synthetic_text_encoder` (seeded stand-in contexts); "clip:<tokenizer dir>" = the
         FrozenCLIPEmbedder mirror on the HIP path (weights from the same source as the UNet's: synthetic seed or the
-        checkpoint's `cond_stage_model.transformer.text_model.*`); or any callable(prompts) -> (B, 77, 768) tensor."""
+        checkpoint's `cond_stage_model.transformer.text_model.*`); bare "clip" is accepted only with synthetic weights (the
+        tokenizer is then the crc32 stand-in, which is meaningless next to real weights); or any callable(prompts) ->
+        (B, 77, 768) tensor."""
         self.apply_canny = apply_canny or _default_canny()
         if isinstance(text_encoder, str) and text_encoder.split(":")[0] == "clip":
             from . import spec as S
             from .ldm.modules.encoders.modules import FrozenCLIPEmbedder
             tok_dir = text_encoder.split(":", 1)[1] if ":" in text_encoder else None
-            text_encoder = FrozenCLIPEmbedder(version=tok_dir, config=S.CLIP_TINY if config == "tiny" else S.CLIP_SD15)
+            synthetic = isinstance(weights, str) and weights.startswith("synthetic")
+            text_encoder = FrozenCLIPEmbedder(version=tok_dir, config=S.CLIP_TINY if config == "tiny" else S.CLIP_SD15,
+                                              allow_hash_tokenizer=synthetic and tok_dir is None)
         self.text_encoder = text_encoder or synthetic_text_encoder
         self.model = create_model(config, cond_stage_model=self.text_encoder)
         if isinstance(weights, str) and weights.startswith("synthetic"):

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include "../../include/sdeo.h"
+#include "sdeo_internal.h"
 #include "kernels.h"
 
 namespace sdeo {

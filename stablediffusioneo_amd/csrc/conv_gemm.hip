@@ -93,7 +93,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
       const int m = m0 + lrow + i * RPP;
       const bool mv = m < p.M;
       if (linear) {
-        vmask[i] = (mv && !(p.dbg & 1)) ? 1u : 0u;
+        vmask[i] = (mv && !dbg_on(p, 1)) ? 1u : 0u;
         xrow[i] = reinterpret_cast<const char*>(p.x) + ((long)m * p.ldx + cl * 8) * 2;
         continue;
       }
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
       const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
       // taps inside the image: rows rlo..rhi-1, columns slo..shi-1
       const int rlo = max(0, -h0), rhi = min(R, Hv - h0), slo = max(0, -w0), shi = min(p.S, Wv - w0);
-      const unsigned sm = (mv && shi > slo && !(p.dbg & 1)) ? (((1u << shi) - 1u) & ~((1u << slo) - 1u)) : 0u;
+      const unsigned sm = (mv && shi > slo && !dbg_on(p, 1)) ? (((1u << shi) - 1u) & ~((1u << slo) - 1u)) : 0u;
       unsigned vm = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r)          // R <= 4 (checked on the host): straight-line selects instead of a divergent loop
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
 #pragma unroll
     for (int i = 0; i < WP; ++i) {
       const int n = n0 + lrow + i * RPP;
-      const bool nv = n < p.N && !(p.dbg & 2);
+      const bool nv = n < p.N && !dbg_on(p, 2);
       wptr[i] = nv ? reinterpret_cast<const char*>(p.w + (size_t)n * p.ldw + (size_t)kbeg * BK + cl * 8) : zero;
       winc[i] = nv ? BK * 2 : 0;
     }
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
         for (int it = 0; it < nk; ++it) {
           retire(it);
           __builtin_amdgcn_s_barrier();
-          if (it + PF < nk && !(p.dbg & 8)) issue((it + PF) % STAGES);
+          if (it + PF < nk && !dbg_on(p, 8)) issue((it + PF) % STAGES);
         }
       }
       __builtin_amdgcn_s_barrier();          // matches the MFMA waves' pre-epilogue barrier (LDS becomes epilogue scratch)
@@ -277,12 +277,12 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
         // MFMAs reading them have issued (an LDS return is >60 clocks away, an MFMA reads its operands at issue).
         f16x8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
         auto reads0 = [&](unsigned sb) {
-          if (p.dbg & 16) return;
+          if (dbg_on(p, 16)) return;
           static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wf0[I.value], wa0 + sb); });
           static_for<MI>([&](auto J) { lds_read128<J.value * 2048>(xf0[J.value], xa0 + sb); });
         };
         auto reads1 = [&](unsigned sb) {
-          if (p.dbg & 16) return;
+          if (dbg_on(p, 16)) return;
           static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wf1[I.value], wa1 + sb); });
           static_for<MI>([&](auto J) { lds_read128<J.value * 2048>(xf1[J.value], xa1 + sb); });
         };
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
           const unsigned sbn = ((it + 1) % STAGES) * STAGE;
           asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NI + MI) : "memory");
           __builtin_amdgcn_sched_barrier(0);
-          if (!(p.dbg & 4)) mma_half(wf0, xf0);
+          if (!dbg_on(p, 4)) mma_half(wf0, xf0);
           __builtin_amdgcn_sched_barrier(0);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
@@ -305,14 +305,14 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
             reads0(sbn);
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (!(p.dbg & 4)) mma_half(wf1, xf1);
+          if (!dbg_on(p, 4)) mma_half(wf1, xf1);
           __builtin_amdgcn_sched_barrier(0);
           if (more) reads1(sbn);
         }
       } else {
         for (int it = 0; it < nk; ++it) {
           __builtin_amdgcn_s_barrier();      // step `it` visible (its loaders retired it before arriving here)
-          if (!(p.dbg & 4)) compute(it);
+          if (!dbg_on(p, 4)) compute(it);
         }
       }
     } else {
@@ -331,10 +331,10 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
   // the waves' private epilogue scratch
   __builtin_amdgcn_s_barrier();
   stamp(p, 3);
-  if (p.dbg & 32) return;
+  if (dbg_on(p, 32)) return;
   static_assert(4 * epilogue_scratch_bytes(TN) <= STAGES * STAGE, "epilogue scratch");
   epilogue<NI, MI, TM, TN>(p, acc, m0, n0, wm, wn, frow, fq, z, bpre, use_bpre, smem + wave * epilogue_scratch_bytes(TN));
-  if (p.dbg & 64) {
+  if (dbg_on(p, 64)) {
     stamp(p, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(p, 5);
@@ -755,7 +755,9 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
     const double xb = (double)p.M * p.Cin * 2.0 * (p.R * p.S > 1 ? 1.3 : 1.0), wb = (double)p.N * p.K * 2.0;
     const double cost_n_fast = xb + 8.0 * wb;
     const double cost_m_fast = (pl.tiles_n < 8 ? pl.tiles_n : 8) * xb + wb * (pl.tiles_n < 8 ? 1.6 : 1.0);
+#ifdef SDEO_DEBUG_KERNELS
     { static const int dbg = [] { const char* e = getenv("SDEO_DBG_GEMM"); return e ? atoi(e) : 0; }(); kp.dbg = dbg; }
+#endif
     kp.n_fastest = g_force_order >= 0 ? g_force_order : (cost_n_fast < cost_m_fast ? 1 : 0);
     static const int epi = [] { const char* e = getenv("SDEO_EPI_COALESCE"); return e ? atoi(e) : 1; }();
     kp.coalesce = epi && p.y && !p.y32 && pl.splitk == 1 && p.act != 3 && !p.bias_per_row && p.N % 8 == 0 && p.ldy % 8 == 0 &&

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP p
   const char* zero = reinterpret_cast<const char*>(g_zero_page);
   stamp(p, 0);
   stamp_cycles(p, 14);
-  if ((p.dbg & 256) && lane == 0) {          // which SIMD each wave of the workgroup landed on (HW_REG_HW_ID)
+  if (dbg_on(p, 256) && lane == 0) {          // which SIMD each wave of the workgroup landed on (HW_REG_HW_ID)
     const int wg = blockIdx.x + gridDim.x * blockIdx.z;
     if (wg < kStampWGs) g_stamps[wg * kStampSlots + wave_all] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
   }
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP p
       }
       __builtin_amdgcn_s_barrier();
       // every MFMA wave now holds K-step it-1 in registers: its W slot and (at tap 0) the previous slice's patch are free
-      if (p.dbg & 8) { if (++tap == 9) { tap = 0; ++cr; } continue; }      // SDEO_DBG_GEMM ablation: no DMAs after the prologue
+      if (dbg_on(p, 8)) { if (++tap == 9) { tap = 0; ++cr; } continue; }      // SDEO_DBG_GEMM ablation: no DMAs after the prologue
       if (tap == 0 && cr + 1 < ncr) issue_x((cr + 1) & 1);
       if (it + PF < nsteps) issue_w((it + PF) % WST);
       if (++tap == 9) { tap = 0; ++cr; }
@@ -189,17 +189,17 @@ __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP p
     __builtin_amdgcn_s_waitcnt(0xc07f);      // retire the kernel-argument loads: see conv_gemm.hip (partial lgkmcnt waits below)
     f16x8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
     auto reads0 = [&](auto T, unsigned wsl, unsigned xoff) {
-      if (p.dbg & 16) return;
+      if (dbg_on(p, 16)) return;
       static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wf0[I.value], wa0 + wsl); });
       static_for<MI>([&](auto J) { lds_read128<0>(xf0[J.value], lds0 + xoff + xrel[T.value][J.value]); });
     };
     auto reads1 = [&](auto T, unsigned wsl, unsigned xoff) {
-      if (p.dbg & 16) return;
+      if (dbg_on(p, 16)) return;
       static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wf1[I.value], wa1 + wsl); });
       static_for<MI>([&](auto J) { lds_read128<0>(xf1[J.value], lds0 + xoff + (xrel[T.value][J.value] ^ 64u)); });
     };
     auto mma_half = [&](const f16x8 (&wf)[NI], const f16x8 (&xf)[MI]) {
-      if (p.dbg & 4) return;
+      if (dbg_on(p, 4)) return;
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -243,14 +243,14 @@ __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP p
   __builtin_amdgcn_s_barrier();
   stamp(p, 3);
   stamp_cycles(p, 15);
-  if (p.dbg & 32) return;
+  if (dbg_on(p, 32)) return;
   static_assert(NMW * epilogue_scratch_bytes(BN) <= 2 * XBYTES + WST * WBYTES, "epilogue scratch");
   epilogue_rows<NI, MI, BN>(p, acc, mrow, n0, fq, z, bpre, use_bpre, smem + wave * epilogue_scratch_bytes(BN));
-  if (p.dbg & 64) {
+  if (dbg_on(p, 64)) {
     stamp(p, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(p, 5);
-    if (p.dbg & 128) {        // the same epilogue once more, now with its code resident: cold instruction fetch vs work
+    if (dbg_on(p, 128)) {        // the same epilogue once more, now with its code resident: cold instruction fetch vs work
       epilogue_rows<NI, MI, BN>(p, acc, mrow, n0, fq, z, bpre, use_bpre, smem + wave * epilogue_scratch_bytes(BN));
       stamp(p, 6);
     }

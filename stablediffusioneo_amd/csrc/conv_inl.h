@@ -24,12 +24,21 @@ struct KP {
   float scale;
   int nk, nk_per_split, splitk;
   int tiles_m, tiles_n;
-  // SDEO_DBG_GEMM (measurement only, results are wrong): 1 = activation DMAs read the zero page, 2 = weight DMAs do,
-  // 4 = no MFMAs, 8 = no DMAs after the prologue, 16 = no fragment reads, 32 = no epilogue
+  // measurement builds only (-DSDEO_DEBUG_KERNELS, `python -m stablediffusioneo_amd.build --debug` -> libsdeo_dbg.so; the
+  // field is ignored by the production kernels): SDEO_DBG_GEMM bits, results are wrong under them: 1 = activation DMAs read
+  // the zero page, 2 = weight DMAs do, 4 = no MFMAs, 8 = no DMAs after the prologue, 16 = no fragment reads, 32 = no epilogue
   int dbg;
   int n_fastest;     // tile order inside an XCD's contiguous run: 1 = all N tiles of an M tile are neighbours
   int coalesce;      // host-checked: the LDS-transposed 16-byte epilogue applies (see epilogue_rows)
 };
+
+// Ablation / stamp switches exist only in the measurement build: in the production library dbg_on() is the constant false and
+// every branch on it (and the stamp code) is compiled out of the K loops.
+#ifdef SDEO_DEBUG_KERNELS
+__device__ __forceinline__ bool dbg_on(const KP& p, int bit) { return (p.dbg & bit) != 0; }
+#else
+__device__ __forceinline__ constexpr bool dbg_on(const KP&, int) { return false; }
+#endif
 
 // SDEO_DBG_GEMM bit 6 (64): per-workgroup phase stamps (s_memrealtime, 100 MHz, chip-wide) written by MFMA wave 0, lane 0:
 // [0] kernel entry, [1] address set-up done, [2] first K-step visible, [3] K loop done, [4] epilogue stores issued,
@@ -37,13 +46,13 @@ struct KP {
 constexpr int kStampWGs = 4096, kStampSlots = 16;
 static __device__ unsigned long long g_stamps[kStampWGs * kStampSlots];
 __device__ __forceinline__ void stamp_cycles(const KP& p, int slot) {      // shader-clock counter (for the in-kernel clock rate)
-  if ((p.dbg & 64) && threadIdx.x == 0) {
+  if (dbg_on(p, 64) && threadIdx.x == 0) {
     const int wg = blockIdx.x + gridDim.x * blockIdx.z;
     if (wg < kStampWGs) g_stamps[wg * kStampSlots + slot] = __builtin_amdgcn_s_memtime();
   }
 }
 __device__ __forceinline__ void stamp(const KP& p, int slot) {
-  if ((p.dbg & 64) && threadIdx.x == 0) {
+  if (dbg_on(p, 64) && threadIdx.x == 0) {
     const int wg = blockIdx.x + gridDim.x * blockIdx.z;
     if (wg < kStampWGs) g_stamps[wg * kStampSlots + slot] = __builtin_amdgcn_s_memrealtime();
   }

@@ -247,7 +247,7 @@ struct sdeo_handle_s {
   std::vector<size_t> ctrl_elems;
   size_t device_bytes = 0;
   // profiling (sdeo_profile_*): HIP events around every launch of the next programs
-  bool autotune = true;     // measure GEMM plans per shape at configure time (SDEO_AUTOTUNE=0 disables)
+  bool autotune = false;    // SDEO_AUTOTUNE=1: measure GEMM plans of untabled shapes at configure time (tuning aid; tools/tune_plans.py)
   bool profiling = false;
   std::vector<ProfRec> prof;
   std::string prof_report;

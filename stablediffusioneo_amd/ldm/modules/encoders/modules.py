@@ -3,11 +3,14 @@
 The reference class (`ldm/modules/encoders/modules.py:90-141`) owns a HuggingFace tokenizer and `CLIPTextModel`, both
 fetched by name from the hub.  Here the transformer runs through libsdeo.so (`sdeo_clip_*`); the tokenizer stays on the
 host and is loaded from LOCAL files only (`version` = a directory holding vocab.json / merges.txt) -- there is no network
-access at run time.  Without such files `HashTokenizer` stands in (deterministic, NOT CLIP's BPE: plumbing only)."""
+access at run time.  Without such files construction FAILS unless the caller opts in to `HashTokenizer`
+(`allow_hash_tokenizer=True`: deterministic, NOT CLIP's BPE -- plumbing for synthetic weights only; loading real weights
+next to it warns, because crc32 ids index the real embedding table at meaningless rows)."""
 from __future__ import annotations
 
 import os
 import re
+import warnings
 import zlib
 from typing import List, Optional, Sequence
 
@@ -46,7 +49,7 @@ class FrozenCLIPEmbedder(AbstractEncoder):
     LAYERS = ["last"]      # the reference also lists "pooled" / "hidden"; cldm_v15 uses the default "last"
 
     def __init__(self, version: Optional[str] = None, device="cuda", max_length=77, freeze=True, layer="last", layer_idx=None,
-                 config: S.ClipConfig = S.CLIP_SD15, runtime: Optional[ClipRuntime] = None):
+                 config: S.ClipConfig = S.CLIP_SD15, runtime: Optional[ClipRuntime] = None, allow_hash_tokenizer: bool = False):
         if layer not in self.LAYERS:
             raise NotImplementedError(f"layer={layer!r}: only 'last' is built (what cldm_v15.yaml uses)")
         self.device = device
@@ -58,6 +61,12 @@ class FrozenCLIPEmbedder(AbstractEncoder):
             from transformers import CLIPTokenizer
             self.tokenizer = CLIPTokenizer.from_pretrained(version, local_files_only=True)
         if self.tokenizer is None:
+            if not allow_hash_tokenizer:
+                raise RuntimeError(
+                    f"FrozenCLIPEmbedder: no local CLIP tokenizer at version={version!r} (a directory with vocab.json + merges.txt is "
+                    f"needed; the reference's default 'openai/clip-vit-large-patch14' is a hub name and there is no network). "
+                    f"Pass allow_hash_tokenizer=True to use the crc32 stand-in -- token ids are then NOT CLIP's BPE ids, which is only "
+                    f"meaningful with synthetic weights.")
             self.tokenizer = HashTokenizer(config.vocab, max_length)
         self.transformer = runtime if runtime is not None else ClipRuntime(config)
 
@@ -65,6 +74,10 @@ class FrozenCLIPEmbedder(AbstractEncoder):
         return self
 
     def load_state_dict(self, sd, strict=False):
+        if isinstance(self.tokenizer, HashTokenizer) and len(sd):
+            warnings.warn("FrozenCLIPEmbedder: checkpoint weights loaded next to the HashTokenizer stand-in: prompts are hashed, not "
+                          "BPE-tokenised, so the conditioning is meaningless for real weights (supply version=<tokenizer dir>)",
+                          RuntimeWarning, stacklevel=2)
         self.transformer.load_state_dict(sd, strict=strict)
         return self
 

@@ -47,6 +47,9 @@ class SdeoRuntime:
         check(self.lib.sdeo_create(C.byref(self._cfg), C.byref(self.handle)), "sdeo_create")
         self.n = self.h = self.w = 0
         self.n_controls = 13
+        # bumped by every sdeo_configure: the library frees and re-plans its arenas / boundary buffers there, so a hipGraph
+        # captured under an older generation points into freed memory and must be re-captured, never replayed
+        self.generation = 0
 
     def __del__(self):
         try:
@@ -122,6 +125,9 @@ class SdeoRuntime:
     def configure(self, n: int, h: int, w: int):
         if (n, h, w) != (self.n, self.h, self.w):
             self._graph_key = None
+            self._graph = None
+            self.generation += 1
+            self.n = self.h = self.w = 0            # a failed configure leaves the handle unconfigured
             check(self.lib.sdeo_configure(self.handle, C.c_int(n), C.c_int(h), C.c_int(w)), "configure")
             self.n, self.h, self.w = n, h, w
         return self
@@ -203,7 +209,7 @@ class SdeoRuntime:
         TensorRT engines the same way, `Engine.py:139-152`).  The graph holds both streams of the step (ControlNet on the
         side stream, UNet encoder on the main one), so the GPU sees the whole fork/join at once.  Inputs are copied into
         fixed device buffers; the returned eps tensor is owned by the runtime (valid until the next call)."""
-        key = (self.n, self.h, self.w, tuple(float(s) for s in (scales or [])), bool(only_mid_control))
+        key = (self.generation, self.n, self.h, self.w, tuple(float(s) for s in (scales or [])), bool(only_mid_control))
         if getattr(self, "_graph_key", None) != key:
             u = self.ucfg
             self._gx = torch.zeros((self.n, u.in_channels, self.h, self.w), dtype=torch.float32, device=self.device)
@@ -252,6 +258,7 @@ class ClipRuntime:
         self._cfg = _lib.SdeoClipConfig(cfg.vocab, cfg.positions, cfg.width, cfg.layers, cfg.heads, cfg.ffn)
         check(self.lib.sdeo_clip_create(C.byref(self._cfg), C.byref(self.handle)), "sdeo_clip_create")
         self.batch = 0
+        self.generation = 0          # bumped by every re-plan of the activation buffers (see SdeoRuntime.generation)
 
     def __del__(self):
         try:
@@ -294,18 +301,25 @@ class ClipRuntime:
         return self
 
     def configure(self, batch: int):
-        check(self.lib.sdeo_clip_configure(self.handle, C.c_int(batch)), "sdeo_clip_configure")
-        self.batch = batch
+        if batch != self.batch:
+            self.generation += 1
+            self.batch = 0
+            check(self.lib.sdeo_clip_configure(self.handle, C.c_int(batch)), "sdeo_clip_configure")
+            self.batch = batch
         return self
 
-    def encode(self, tokens: torch.Tensor) -> torch.Tensor:
-        """tokens: integer [batch, positions] -> fp32 [batch, positions, width] on the device."""
+    def encode(self, tokens: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """tokens: integer [batch, positions] -> fp32 [batch, positions, width] on the device (into `out` when given)."""
         if tokens.dim() != 2 or tokens.shape[1] != self.cfg.positions:
             raise ValueError(f"tokens must be [batch, {self.cfg.positions}], got {tuple(tokens.shape)}")
         if tokens.shape[0] != self.batch:
             self.configure(int(tokens.shape[0]))
         tok = tokens.to(device=self.device, dtype=torch.int32).contiguous()
-        out = torch.empty((self.batch, self.cfg.positions, self.cfg.width), dtype=torch.float32, device=self.device)
+        shape = (self.batch, self.cfg.positions, self.cfg.width)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
+            raise _lib.SdeoError(f"encode: out must be a contiguous fp32 tensor of shape {shape}")
         check(self.lib.sdeo_clip_encode(self.handle, ptr(tok), C.c_int(self.batch), ptr(out), cur_stream()), "sdeo_clip_encode")
         return out
 

@@ -65,11 +65,11 @@ def test_frozen_clip_embedder_mirror():
     from stablediffusioneo_amd.ldm.modules.encoders.modules import FrozenCLIPEmbedder
     from stablediffusioneo_amd.runtime import ClipRuntime
     sd, _, _ = load_gold()
-    enc = FrozenCLIPEmbedder(config=S.CLIP_TINY, runtime=ClipRuntime(S.CLIP_TINY).load_state_dict(sd))
+    enc = FrozenCLIPEmbedder(config=S.CLIP_TINY, runtime=ClipRuntime(S.CLIP_TINY).load_state_dict(sd), allow_hash_tokenizer=True)
     prompts = ["a bird, best quality, extremely detailed", "lowres, bad anatomy"]
     z = enc.encode(prompts)
     assert z.shape == (2, 77, 64) and z.dtype == torch.float32 and z.is_cuda
     want = clip_text_forward(sd, enc.tokenize(prompts), S.CLIP_TINY.heads)
     assert rel_err(z, want) < REL
     with pytest.raises(NotImplementedError):
-        FrozenCLIPEmbedder(layer="pooled", config=S.CLIP_TINY, runtime=enc.transformer)
+        FrozenCLIPEmbedder(layer="pooled", config=S.CLIP_TINY, runtime=enc.transformer, allow_hash_tokenizer=True)

@@ -72,10 +72,19 @@ def test_tiny_nets_vs_reference_golden(tiny_rt, n, h, w, t):
     from stablediffusioneo_amd.runtime import CONTEXT_CACHED, HINT_CACHED
     eps3 = rt.apply_model(x, None, tt, None, scales=[1.0] * 13, flags=HINT_CACHED | CONTEXT_CACHED)
     assert torch.equal(eps2, eps3)
-    # VAE decoder (the golden feeds x straight into Decoder.forward: undo decode_first_stage's 1/scale_factor and
-    # make post_quant_conv the identity for this check)
-    img = rt.vae_decode(x[:1] if n > 1 else x)
-    assert img.shape == (1, 3, 8 * h, 8 * w)
+    # VAE Decoder.forward against the reference Decoder's own output: the golden feeds x straight into Decoder.forward, so
+    # undo decode_first_stage's 1/scale_factor and make post_quant_conv the identity for this check (restored afterwards)
+    pq_w, pq_b = "first_stage_model.post_quant_conv.weight", "first_stage_model.post_quant_conv.bias"
+    zc = S.VAE_TINY.z_channels
+    try:
+        rt.load_tensor(pq_w, torch.eye(zc).reshape(zc, zc, 1, 1))
+        rt.load_tensor(pq_b, torch.zeros(zc))
+        img = rt.vae_decode(x * S.VAE_TINY.scale_factor)
+        assert img.shape == (n, 3, 8 * h, 8 * w)
+        check(img, g[f"{tag}.dec"], f"{tag} Decoder.forward (reference golden)")
+    finally:
+        rt.load_tensor(pq_w, S.synth_tensor(pq_w, (zc, zc, 1, 1), 0))
+        rt.load_tensor(pq_b, S.synth_tensor(pq_b, (zc,), 0))
 
 
 def test_control_scales_and_only_mid(tiny_rt):

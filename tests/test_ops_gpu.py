@@ -315,6 +315,9 @@ ATTN_CASES = [  # (B, heads, Tq, Tk, d)
     (2, 8, 1024, 1024, 40), (2, 8, 256, 256, 80), (2, 8, 256, 256, 160), (2, 8, 64, 64, 160),
     (2, 8, 1024, 77, 40), (2, 8, 256, 77, 80), (2, 8, 64, 77, 160),
     (2, 4, 128, 128, 16), (2, 4, 200, 77, 32), (1, 4, 100, 100, 64), (2, 8, 70, 70, 8),
+    # token counts of the benchmarked configurations: 64x64 latent (T = 4096, BASELINE configs[1]) and 96x96 (T = 9216 /
+    # 2304, configs[3]); B = 1 and 2 heads keep the fp32 reference's score tensor small
+    (1, 2, 4096, 4096, 40), (1, 2, 4096, 77, 40), (1, 2, 9216, 9216, 40), (1, 2, 2304, 2304, 80), (1, 2, 9216, 77, 40),
 ]
 
 

@@ -242,3 +242,47 @@ def test_full_sd15_lat8():
         for i, c in enumerate(ctrl):
             close(c, g[f"control{i}"], atol=ATOL * max(1.0, float(np.abs(g[f"control{i}"]).max())))
         close(O.unet_forward(su, S.unet_plan(ucfg), x, t, ctx, ctrl), g["eps"], atol=ATOL * max(1.0, float(np.abs(g["eps"]).max())))
+
+
+# ---------------------------------------------------------------- benchmarked configurations (tests/golden/sd15_full.npz)
+
+def _full():
+    path = os.path.join(GOLDEN, "sd15_full.npz")
+    if not os.path.exists(path):
+        pytest.skip("sd15_full.npz not generated")
+    return np.load(path)
+
+
+@pytest.mark.parametrize("hh", [8, 16])
+def test_sd15_vae_decoder_small_latents(hh):
+    """The oracle's Decoder restatement with the SD-1.5 VAE configuration (ch 128, 512-channel mid block, d = 512 attention)
+    against the reference Decoder's own output."""
+    g = _full()
+    v = S.VAE_SD15
+    sv = S.synth_state_dict(S.param_spec_vae(v), 0, S.NS_VAE)
+    with torch.no_grad():
+        img = O.decode_first_stage(sv, S.vae_plan(v)[1], torch.tensor(g[f"vae{hh}.z"]), v.scale_factor)
+    ref = g[f"vae{hh}.image"]
+    close(img, ref, atol=ATOL * max(1.0, float(np.abs(ref).max())))
+
+
+@pytest.mark.slow
+def test_full_sd15_pass64():
+    """BASELINE configs[1] shape (latent 64x64, fused CFG pair N=2): oracle vs the reference modules' eps and controls."""
+    g = _full()
+    ucfg = S.UNET_SD15
+    su = S.synth_state_dict(S.param_spec_unet(ucfg), 0, S.NS_UNET)
+    sc = S.synth_state_dict(S.param_spec_controlnet(ucfg), 0, S.NS_CONTROL)
+    x1 = randn((1, 4, 64, 64), 2946901)
+    from tests.common import make_hint
+    hint1 = make_hint(1, 512, 512)
+    x, hint = torch.cat([x1, x1]), torch.cat([hint1, hint1])
+    ctx = torch.cat([randn((1, 77, 768), 1), randn((1, 77, 768), 2)])
+    t = torch.tensor([951, 951], dtype=torch.long)
+    with torch.no_grad():
+        ctrl = O.controlnet_forward(sc, S.unet_plan(ucfg, False), S.hint_block_convs(ucfg), x, hint, t, ctx)
+        for i, c in enumerate(ctrl):
+            ref = g[f"pass64.control{i}.sub"]
+            close(c[:, ::40].contiguous(), ref, atol=ATOL * max(1.0, float(g[f"pass64.control{i}.stats"][0])))
+        eps = O.unet_forward(su, S.unet_plan(ucfg), x, t, ctx, ctrl)
+        close(eps, g["pass64.eps"], atol=ATOL * max(1.0, float(np.abs(g["pass64.eps"]).max())))

@@ -280,7 +280,7 @@ def test_hackathon_process_with_clip_text_encoder(tiny_model):
     from stablediffusioneo_amd.ldm.modules.encoders.modules import FrozenCLIPEmbedder
     from stablediffusioneo_amd.runtime import ClipRuntime
     ccfg = S.ClipConfig(vocab=1000, positions=77, width=tiny_model.rt.ucfg.context_dim, layers=2, heads=4, ffn=192)
-    enc = FrozenCLIPEmbedder(config=ccfg, runtime=ClipRuntime(ccfg).load_synthetic(5))
+    enc = FrozenCLIPEmbedder(config=ccfg, runtime=ClipRuntime(ccfg).load_synthetic(5), allow_hash_tokenizer=True)
     hk = c2i.hackathon()
     hk.apply_canny = lambda img, lo, hi: ((np.random.RandomState(3).rand(*img.shape[:2]) < 0.08) * 255).astype(np.uint8)
     hk.text_encoder = enc

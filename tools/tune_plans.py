@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 from stablediffusioneo_amd import _lib, spec as S                 # noqa: E402
 from stablediffusioneo_amd.runtime import SdeoRuntime             # noqa: E402
 
+os.environ.setdefault("SDEO_AUTOTUNE", "1")      # measure every untabled shape on this device
 lib = _lib.load()
 start = len(_lib.dump_tuned_plans(lib))
 rt = SdeoRuntime(S.UNET_SD15, S.VAE_SD15)
