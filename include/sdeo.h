@@ -79,16 +79,16 @@ int sdeo_gemm_f16(void* y, int ldy, const void* x, int ldx, const void* w, int l
 int sdeo_layernorm_f16(void* y, const void* x, const float* gamma, const float* beta, int rows, int c, float eps,
                        void* stream);
 
-/* Fused attention O = softmax(Q K^T scale) V.  Q [b][tq][ldq], K [b][tk_stride][ldk] (head h at column h*d),
- * V TRANSPOSED: vt[(h*d+i)*ldvt + b*vt_batch_stride + j] (vt_batch_stride % 8 == 0);  O [b][tq][ldo].
- * Keys >= tk are masked. */
-int sdeo_attention_f16(void* o, int ldo, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int b,
-                       int heads, int tq, int tk, int tk_stride, int vt_batch_stride, int d, float scale, void* stream);
+/* Fused attention O = softmax(Q K^T scale) V.  Q [b][tq][ldq], K [b][tk_stride][ldk], V [b][v_batch_stride][ldv] (all
+ * row-major, head h at column h*d: column blocks of one fused q/k/v projection work as they are);  O [b][tq][ldo].
+ * Keys >= tk are masked.  Operands 16-byte aligned, ld* multiples of 8. */
+int sdeo_attention_f16(void* o, int ldo, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int b,
+                       int heads, int tq, int tk, int tk_stride, int v_batch_stride, int d, float scale, void* stream);
 
 /* as sdeo_attention_f16 with the causal mask of the CLIP text transformer: key j is masked for query t when j > t
  * (needs tq == tk) */
-int sdeo_attention_causal_f16(void* o, int ldo, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int b,
-                              int heads, int tq, int tk, int tk_stride, int vt_batch_stride, int d, float scale,
+int sdeo_attention_causal_f16(void* o, int ldo, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int b,
+                              int heads, int tq, int tk, int tk_stride, int v_batch_stride, int d, float scale,
                               void* stream);
 
 /* GEGLU: y[r][0:c] = a[r][0:c] * gelu_erf(a[r][c:2c]) */

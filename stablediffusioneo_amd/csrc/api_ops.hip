@@ -122,20 +122,54 @@ int sdeo_gemm_f16(void* y, int ldy, const void* x, int ldx, const void* w, int l
   return conv_gemm(p, S(stream));
 }
 
+int sdeo_debug_fold_layernorm(void* w_out, float* s_out, float* b_out, const void* w, const float* gamma, const float* beta,
+                              const float* bias, int rows, int c, void* stream) {
+  return fold_layernorm((f16*)w_out, s_out, b_out, (const f16*)w, gamma, beta, bias, rows, c, S(stream));
+}
+
+int sdeo_debug_gemm_stats_f16(void* y, int ldy, const void* x, int ldx, const void* w, int ldw, const float* bias, const void* res,
+                              int ldres, int m, int n, int k, float* stats, int stats_ld, int* strips_out, void* stream) {
+  SDEO_CHECK(stats && strips_out, "gemm_stats: null argument");
+  ConvGemm p;
+  fill_gemm(p, m, n, k);
+  p.x = (const f16*)x; p.w = (const f16*)w; p.bias = bias; p.res = (const f16*)res; p.y = (f16*)y;
+  p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldres = ldres;
+  *strips_out = conv_gemm_stats_strips(p);
+  if (*strips_out == 0) return 0;
+  SDEO_CHECK(*strips_out <= stats_ld, "gemm_stats: %d strips do not fit stats_ld %d", *strips_out, stats_ld);
+  p.stats_out = stats; p.stats_ld = stats_ld;
+  return conv_gemm(p, S(stream));
+}
+
+int sdeo_debug_gemm_ln_f16(void* y, int ldy, const void* x, int ldx, const void* w_folded, int ldw, const float* ln_s,
+                           const float* bias_folded, const float* stats, int stats_ld, int strips, int ln_c, int m, int n, int k, int act, float eps, void* workspace, size_t workspace_bytes, void* stream) {
+  ConvGemm p;
+  fill_gemm(p, m, n, k);
+  p.x = (const f16*)x; p.w = (const f16*)w_folded; p.bias = bias_folded; p.y = (f16*)y;
+  p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.act = act;
+  p.ln_stats = stats; p.ln_s = ln_s; p.ln_strips = strips; p.ln_ld = stats_ld; p.ln_c = ln_c; p.ln_eps = eps;
+  p.workspace = (float*)workspace; p.workspace_bytes = workspace_bytes;
+  return conv_gemm(p, S(stream));
+}
+
+int sdeo_debug_row_stats_f16(float* stats, int stats_ld, const void* x, int ldx, int rows, int c, void* stream) {
+  return row_stats(stats, stats_ld, (const f16*)x, ldx, rows, c, S(stream));
+}
+
 int sdeo_layernorm_f16(void* y, const void* x, const float* gamma, const float* beta, int rows, int c, float eps,
                        void* stream) {
   return layernorm((f16*)y, c, (const f16*)x, c, gamma, beta, rows, c, eps, S(stream));
 }
 
-int sdeo_attention_f16(void* o, int ldo, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int b,
+int sdeo_attention_f16(void* o, int ldo, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int b,
                        int heads, int tq, int tk, int tk_stride, int vt_batch_stride, int d, float scale, void* stream) {
-  return attention((f16*)o, ldo, (const f16*)q, ldq, (const f16*)k, ldk, (const f16*)vt, ldvt, b, heads, tq, tk, tk_stride,
+  return attention((f16*)o, ldo, (const f16*)q, ldq, (const f16*)k, ldk, (const f16*)v, ldv, b, heads, tq, tk, tk_stride,
                    vt_batch_stride, d, scale, S(stream));
 }
 
-int sdeo_attention_causal_f16(void* o, int ldo, const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, int b,
+int sdeo_attention_causal_f16(void* o, int ldo, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int b,
                               int heads, int tq, int tk, int tk_stride, int vt_batch_stride, int d, float scale, void* stream) {
-  return attention((f16*)o, ldo, (const f16*)q, ldq, (const f16*)k, ldk, (const f16*)vt, ldvt, b, heads, tq, tk, tk_stride,
+  return attention((f16*)o, ldo, (const f16*)q, ldq, (const f16*)k, ldk, (const f16*)v, ldv, b, heads, tq, tk, tk_stride,
                    vt_batch_stride, d, scale, S(stream), 1);
 }
 

@@ -12,23 +12,30 @@
 //    of the next MFMA (O^T += V^T P^T) with no LDS round trip.  The k-order inside a step is permuted
 //    (element j of lane-half h is key 16s + 8(j>>2) + 4h + (j&3)); the V^T fragment is fetched with two
 //    8-byte LDS reads at exactly those key offsets.
-//  * V is consumed transposed: the caller supplies V^T ([heads*d][B*TkS], produced directly by the
-//    projection GEMM with swapped operands), so both MFMA operands are contraction-contiguous in memory and
-//    the kernel needs no in-LDS transpose.
+//  * V arrives row-major ([B*TkS][heads*d], i.e. a column block of the fused q/k/v projection) and is staged
+//    row-major in LDS ([key][d]); the V^T fragments of the O^T += V^T P^T MFMA are fetched with the transposing
+//    LDS read ds_read_b64_tr_b16 (four keys of one channel per lane), so no transposed copy of V exists anywhere.
+//    The key-row stride of the LDS tile is 64 or 192 bytes mod 256: the four rows a 32-lane half reads then
+//    cover all 64 banks once.
 //  * head dims 40 / 80 / 160 (and 8..64 for the reduced test config): QK^T pads d to a multiple of 16 with
 //    zero chunks in LDS, PV pads to a multiple of 32 rows.
-//  * K / V^T tiles are register-staged and double-buffered: the next tile's global loads are issued before
+//  * K / V tiles are register-staged and double-buffered: the next tile's global loads are issued before
 //    the MFMA phase and written to the other LDS buffer after it.
 #include "kernels.h"
 
 namespace sdeo {
 
+typedef __fp16 h16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+// bytes per key of the row-major V tile in LDS (see the file comment)
+constexpr int attn_vrow(int dt) { return dt == 1 ? 64 : (dt <= 3 ? 192 : 320); }
+
 struct AP {
   f16* o;
   const f16* q;
   const f16* k;
-  const f16* vt;
-  int ldo, ldq, ldk, ldvt;
+  const f16* v;
+  int ldo, ldq, ldk, ldv;
   int H, Tq, Tk, TkS, TkSv, d;
   float scale_log2;
   int causal;        // 1: key j is visible to query t only when j <= t (CLIP text transformer)
@@ -45,15 +52,14 @@ void attention_kernel(const AP p) {
   constexpr int NKB = 2 / KS;                                // 32-key blocks of a tile each wave handles
   constexpr int DT = (D16 + 1) / 2;                          // 32-row tiles of O^T
   constexpr int KROW = D16 * 32 + ((D16 * 2) % 2 == 0 ? 16 : 0);  // K tile row bytes (odd multiple of 16)
-  constexpr int VROW = 64 * 2 + 8;                           // V^T tile row bytes (odd multiple of 8)
+  constexpr int VROW = attn_vrow(DT);                        // V tile bytes per key: >= DT*64, == 64 or 192 (mod 256)
   constexpr int KBYTES = 64 * KROW;
-  constexpr int VBYTES = DT * 32 * VROW;
+  constexpr int VBYTES = 64 * VROW;
   constexpr int STAGE = KBYTES + VBYTES;
-  constexpr int KCH = D16 * 2;                               // 16-byte chunk slots per K row
+  constexpr int KCH = D16 * 2;                               // 16-byte chunk slots per K / V row
   constexpr int KITEMS = 64 * KCH, KPASS = (KITEMS + NT - 1) / NT;
-  constexpr int VITEMS = DT * 32 * 8, VPASS = (VITEMS + NT - 1) / NT;
-  // Row sum for free (odd D16 only): P V pads d to DT*32 = 16 (D16 + 1) rows of O^T, QK^T only to 16 D16, so row R1 = 16 D16 of
-  // the V^T tile is never a real channel.  Filled with ones, the MFMA leaves sum_k P[k][q] in that row of O^T (register 8 of the
+  // Row sum for free (odd D16 only): P V pads d to DT*32 = 16 (D16 + 1) rows of O^T, QK^T only to 16 D16, so column R1 = 16 D16 of
+  // the V tile is never a real channel.  Filled with ones, the MFMA leaves sum_k P[k][q] in that row of O^T (register 8 of the
   // last tile, lanes 0..31): no per-score add, no cross-half exchange per tile, and the running sum is rescaled with O.
   constexpr bool ONES = (D16 % 2) == 1;
   constexpr int R1 = 16 * D16;
@@ -92,17 +98,16 @@ void attention_kernel(const AP p) {
   }
 
   const f16* kbase = p.k + (size_t)b * p.TkS * p.ldk + h * d;
-  const f16* vbase = p.vt + (size_t)h * d * p.ldvt + (size_t)b * p.TkSv;
+  const f16* vbase = p.v + (size_t)b * p.TkSv * p.ldv + h * d;
   const int ntiles = (p.Tk + 63) / 64;
   const f16x8 zero8 = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
 
   // per-thread staging state, hoisted out of the key loop: source pointers (advanced by one tile per call) and LDS
   // destinations of the 16-byte chunks this thread moves
-  f16x8 kr[KPASS], vr[VPASS];
+  f16x8 kr[KPASS], vr[KPASS];
   const f16* kptr[KPASS];
-  const f16* vptr[VPASS];
-  int krow[KPASS], kdst[KPASS], vkey[VPASS], vdst[VPASS];
-  bool vones[VPASS];
+  const f16* vptr[KPASS];
+  int krow[KPASS], kdst[KPASS], vdst[KPASS];
 #pragma unroll
   for (int i = 0; i < KPASS; ++i) {
     const int it = tid + i * NT;
@@ -110,56 +115,36 @@ void attention_kernel(const AP p) {
     const bool use = it < KITEMS && c * 8 < d;
     krow[i] = use ? row : (1 << 30);                 // never valid
     kptr[i] = kbase + (size_t)row * p.ldk + c * 8;
+    vptr[i] = vbase + (size_t)row * p.ldv + c * 8;
     kdst[i] = it < KITEMS ? row * KROW + c * 16 : -1;
+    vdst[i] = use ? row * VROW + c * 16 : -1;        // chunk slots past d keep their zeros / the ones column
   }
-#pragma unroll
-  for (int i = 0; i < VPASS; ++i) {
-    const int it = tid + i * NT;
-    const int row = it >> 3, c = it & 7;
-    const bool use = it < VITEMS && row < d;
-    vkey[i] = use ? c * 8 : (1 << 30);
-    vones[i] = ONES && it < VITEMS && row == R1;
-    vptr[i] = vbase + (size_t)row * p.ldvt + c * 8;
-    vdst[i] = it < VITEMS ? row * VROW + c * 16 : -1;
-  }
-  const size_t kstep = (size_t)64 * p.ldk;
+  const size_t kstep = (size_t)64 * p.ldk, vstep = (size_t)64 * p.ldv;
   auto load_tile = [&](int kt) {
     const int key0 = kt * 64;
 #pragma unroll
     for (int i = 0; i < KPASS; ++i) {
-      kr[i] = (key0 + krow[i] < p.Tk) ? *reinterpret_cast<const f16x8*>(kptr[i]) : zero8;
+      const bool ok = key0 + krow[i] < p.Tk;        // rows >= Tk: K zero (masked anyway), V zero (P is 0 there, V must be finite)
+      kr[i] = ok ? *reinterpret_cast<const f16x8*>(kptr[i]) : zero8;
+      vr[i] = ok ? *reinterpret_cast<const f16x8*>(vptr[i]) : zero8;
       kptr[i] += kstep;
-    }
-#pragma unroll
-    for (int i = 0; i < VPASS; ++i) {
-      const int key = key0 + vkey[i];
-      f16x8 v = vones[i] ? f16x8{(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f} : zero8;
-      if (key < p.Tk) {
-        v = *reinterpret_cast<const f16x8*>(vptr[i]);
-        if (key + 8 > p.Tk) {  // partially valid chunk: zero the keys >= Tk (P is 0 there, V must be finite)
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (key + j >= p.Tk) v[j] = (f16)0.f;
-        }
-      }
-      vr[i] = v;
-      vptr[i] += 64;
+      vptr[i] += vstep;
     }
   };
   auto store_tile = [&](int stage) {
     char* ks_ = smem + stage * STAGE;
     char* vs_ = ks_ + KBYTES;
 #pragma unroll
-    for (int i = 0; i < KPASS; ++i)
+    for (int i = 0; i < KPASS; ++i) {
       if (kdst[i] >= 0) *reinterpret_cast<f16x8*>(ks_ + kdst[i]) = kr[i];
-#pragma unroll
-    for (int i = 0; i < VPASS; ++i)
-      if (vdst[i] >= 0) {
-        f16x4* dst = reinterpret_cast<f16x4*>(vs_ + vdst[i]);   // rows are only 8-byte aligned
-        dst[0] = __builtin_shufflevector(vr[i], vr[i], 0, 1, 2, 3);
-        dst[1] = __builtin_shufflevector(vr[i], vr[i], 4, 5, 6, 7);
-      }
+      if (vdst[i] >= 0) *reinterpret_cast<f16x8*>(vs_ + vdst[i]) = vr[i];
+    }
   };
+  // the V tiles start as zeros (+ the ones column): staging only ever writes the chunk slots below d
+  for (int st = 0; st < 2; ++st)
+    for (int off = tid * 16; off < VBYTES; off += NT * 16) *reinterpret_cast<f16x8*>(smem + st * STAGE + KBYTES + off) = zero8;
+  __syncthreads();
+  if (ONES && tid < 128) *reinterpret_cast<f16*>(smem + (tid >> 6) * STAGE + KBYTES + (tid & 63) * VROW + R1 * 2) = (f16)1.f;
 
   f32x16 o[DT];
 #pragma unroll
@@ -241,13 +226,15 @@ void attention_kernel(const AP p) {
         f16x8 pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (f16)s[ki][8 * st + j];
-        const int kofs = (kb * 32 + 16 * st + 4 * lh) * 2;
+        // V^T fragment by transposing reads: lane (q = (lane & 15) >> 2, pp = lane & 3) of each 16-lane group addresses key row
+        // q, channels 4pp..4pp+3 of the group's 4-key x 16-channel block and receives its own channel for the four keys
+        const char* vblk = vs_ + (kb * 32 + 16 * st + 4 * lh + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
-          const char* vrow = vs_ + (t * 32 + lq) * VROW + kofs;
-          const f16x4 lo = *reinterpret_cast<const f16x4*>(vrow);
-          const f16x4 hi = *reinterpret_cast<const f16x4*>(vrow + 16);
-          const f16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          typedef __attribute__((address_space(3))) h16x4* lds_h4;
+          const h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(vblk + t * 64));
+          const h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(vblk + t * 64 + 8 * VROW));
+          const f16x8 vf = __builtin_shufflevector(__builtin_bit_cast(f16x4, lo), __builtin_bit_cast(f16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
           o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
         }
       }
@@ -306,7 +293,7 @@ template <int D16, int KS>
 static int launch_attn_ks(const AP& ap, int B, hipStream_t stream) {
   constexpr int DT = (D16 + 1) / 2;
   constexpr int KROW = D16 * 32 + ((D16 * 2) % 2 == 0 ? 16 : 0);
-  constexpr int stage2 = 2 * (64 * KROW + DT * 32 * (64 * 2 + 8));
+  constexpr int stage2 = 2 * (64 * KROW + 64 * attn_vrow(DT));
   constexpr int merge = KS == 2 ? 4 * (2 + DT * 16) * 64 * 4 : 0;     // LDS of the key-half merge
   constexpr int smem = stage2 > merge ? stage2 : merge;
   static bool attr_done = false;
@@ -337,16 +324,19 @@ static int launch_attn(const AP& ap, int B, hipStream_t stream) {
   return launch_attn_ks<D16, 1>(ap, B, stream);
 }
 
-int attention(f16* o, int ldo, const f16* q, int ldq, const f16* k, int ldk, const f16* vt, int ldvt, int B, int H,
+int attention(f16* o, int ldo, const f16* q, int ldq, const f16* k, int ldk, const f16* v, int ldv, int B, int H,
               int Tq, int Tk, int TkS, int TkSv, int d, float scale, hipStream_t stream, int causal) {
-  SDEO_CHECK(o && q && k && vt, "attention: null operand");
+  SDEO_CHECK(o && q && k && v, "attention: null operand");
   SDEO_CHECK(B > 0 && H > 0 && Tq > 0 && Tk > 0 && TkS >= Tk && TkSv >= Tk, "attention: bad sizes B=%d H=%d Tq=%d Tk=%d TkS=%d TkSv=%d", B,
              H, Tq, Tk, TkS, TkSv);
   SDEO_CHECK(d % 8 == 0 && d >= 8 && d <= 160, "attention: head dim %d unsupported (multiple of 8, <= 160)", d);
-  SDEO_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0 && TkSv % 8 == 0,
-             "attention: strides must keep 16-byte alignment (ldq=%d ldk=%d ldvt=%d ldo=%d TkSv=%d)", ldq, ldk, ldvt, ldo, TkSv);
+  SDEO_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0,
+             "attention: strides must keep 16-byte alignment (ldq=%d ldk=%d ldv=%d ldo=%d)", ldq, ldk, ldv, ldo);
+  SDEO_CHECK((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (reinterpret_cast<uintptr_t>(k) & 15) == 0 &&
+                 (reinterpret_cast<uintptr_t>(v) & 15) == 0 && (reinterpret_cast<uintptr_t>(o) & 7) == 0,
+             "attention: operands must be 16-byte aligned");
   SDEO_CHECK(!causal || Tq == Tk, "attention: causal needs Tq == Tk (got %d, %d)", Tq, Tk);
-  AP ap{o, q, k, vt, ldo, ldq, ldk, ldvt, H, Tq, Tk, TkS, TkSv, d, scale * 1.4426950408889634f, causal ? 1 : 0};
+  AP ap{o, q, k, v, ldo, ldq, ldk, ldv, H, Tq, Tk, TkS, TkSv, d, scale * 1.4426950408889634f, causal ? 1 : 0};
   const int d16 = cdiv(d, 16);
   switch (d16) {
     case 1: return launch_attn<1>(ap, B, stream);

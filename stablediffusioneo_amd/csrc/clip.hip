@@ -73,14 +73,14 @@ static void build_registry(Clip* e) {
   add_w(e, "embeddings.position_embedding.weight", true, c.positions, W, take((size_t)c.positions * W * 2));
   for (int l = 0; l < c.layers; ++l) {
     const std::string p = "encoder.layers." + std::to_string(l) + ".";
-    // q_proj and k_proj stacked: one [2W][W] matrix and one [2W] bias
-    const size_t qk = take((size_t)2 * W * W * 2), qkb = take((size_t)2 * W * 4);
-    add_w(e, p + "self_attn.q_proj.weight", true, W, W, qk);
-    add_w(e, p + "self_attn.k_proj.weight", true, W, W, qk + (size_t)W * W * 2);
-    add_w(e, p + "self_attn.q_proj.bias", false, W, 0, qkb);
-    add_w(e, p + "self_attn.k_proj.bias", false, W, 0, qkb + (size_t)W * 4);
-    add_w(e, p + "self_attn.v_proj.weight", true, W, W, take((size_t)W * W * 2));
-    add_w(e, p + "self_attn.v_proj.bias", false, W, 0, take((size_t)W * 4));
+    // q_proj, k_proj and v_proj stacked: one [3W][W] matrix and one [3W] bias (one GEMM; the attention kernel reads V row-major)
+    const size_t qkv = take((size_t)3 * W * W * 2), qkvb = take((size_t)3 * W * 4);
+    add_w(e, p + "self_attn.q_proj.weight", true, W, W, qkv);
+    add_w(e, p + "self_attn.k_proj.weight", true, W, W, qkv + (size_t)W * W * 2);
+    add_w(e, p + "self_attn.v_proj.weight", true, W, W, qkv + (size_t)2 * W * W * 2);
+    add_w(e, p + "self_attn.q_proj.bias", false, W, 0, qkvb);
+    add_w(e, p + "self_attn.k_proj.bias", false, W, 0, qkvb + (size_t)W * 4);
+    add_w(e, p + "self_attn.v_proj.bias", false, W, 0, qkvb + (size_t)2 * W * 4);
     add_w(e, p + "self_attn.out_proj.weight", true, W, W, take((size_t)W * W * 2));
     add_w(e, p + "self_attn.out_proj.bias", false, W, 0, take((size_t)W * 4));
     add_w(e, p + "layer_norm1.weight", false, W, 0, take((size_t)W * 4));
@@ -211,19 +211,18 @@ int sdeo_clip_configure(sdeo_clip_handle h, int batch) {
   Clip* e = h;
   const sdeo_clip_config& c = e->cfg;
   const int B = batch, T = c.positions, W = c.width, F = c.ffn, H = c.heads, d = W / H;
-  const int rows = B * T, TS = (T + 7) / 8 * 8;
-  // activation buffers (fp16): xa, xb, a [rows][W]; qk [rows][2W]; v [rows][W]; vt [W][B*TS]; o [rows][W]; hid [rows][F]
+  const int rows = B * T;
+  // activation buffers (fp16): xa, xb, a [rows][W]; qkv [rows][3W]; o [rows][W]; hid [rows][F]
   size_t off = 0;
   auto take = [&](size_t elems) { const size_t o = align256(off); off = o + elems * 2; return o; };
   const size_t o_xa = take((size_t)rows * W), o_xb = take((size_t)rows * W), o_a = take((size_t)rows * W),
-               o_qk = take((size_t)rows * 2 * W), o_v = take((size_t)rows * W), o_vt = take((size_t)W * B * TS),
-               o_o = take((size_t)rows * W), o_h = take((size_t)rows * F);
+               o_qkv = take((size_t)rows * 3 * W), o_o = take((size_t)rows * W), o_h = take((size_t)rows * F);
   e->act_bytes = align256(off);
   SDEO_HIP(hipMalloc((void**)&e->act, e->act_bytes));
-  SDEO_HIP(hipMemset(e->act, 0, e->act_bytes));          // the padded columns of vt stay zero
+  SDEO_HIP(hipMemset(e->act, 0, e->act_bytes));
   SDEO_HIP(hipMalloc((void**)&e->tokens, (size_t)rows * sizeof(int32_t)));
   auto P = [&](size_t o) { return reinterpret_cast<f16*>(e->act + o); };
-  f16 *xa = P(o_xa), *xb = P(o_xb), *a = P(o_a), *qk = P(o_qk), *v = P(o_v), *vt = P(o_vt), *o = P(o_o), *hid = P(o_h);
+  f16 *xa = P(o_xa), *xb = P(o_xb), *a = P(o_a), *qkv = P(o_qkv), *o = P(o_o), *hid = P(o_h);
 
   size_t ws = 0;
   auto gemm = [&](const f16* x, int K, const f16* w, int N, const float* bias, int act, const f16* res, f16* y) {
@@ -251,11 +250,9 @@ int sdeo_clip_configure(sdeo_clip_handle h, int batch) {
     const float *g1 = vp(e, p + "layer_norm1.weight"), *b1 = vp(e, p + "layer_norm1.bias");
     const float *g2 = vp(e, p + "layer_norm2.weight"), *b2 = vp(e, p + "layer_norm2.bias");
     { const f16* xi = x; e->prog.push_back([=](hipStream_t s) { return layernorm(a, W, xi, W, g1, b1, rows, W, 1e-5f, s); }); }
-    gemm(a, W, wp(e, p + "self_attn.q_proj.weight"), 2 * W, vp(e, p + "self_attn.q_proj.bias"), 0, nullptr, qk);
-    gemm(a, W, wp(e, p + "self_attn.v_proj.weight"), W, vp(e, p + "self_attn.v_proj.bias"), 0, nullptr, v);
-    e->prog.push_back([=](hipStream_t s) { return transpose_pad(vt, B * TS, v, W, B, T, TS, W, s); });
+    gemm(a, W, wp(e, p + "self_attn.q_proj.weight"), 3 * W, vp(e, p + "self_attn.q_proj.bias"), 0, nullptr, qkv);
     e->prog.push_back([=](hipStream_t s) {
-      return attention(o, W, qk, 2 * W, qk + W, 2 * W, vt, B * TS, B, H, T, T, T, TS, d, scale, s, /*causal=*/1);
+      return attention(o, W, qkv, 3 * W, qkv + W, 3 * W, qkv + 2 * W, 3 * W, B, H, T, T, T, T, d, scale, s, /*causal=*/1);
     });
     gemm(o, W, wp(e, p + "self_attn.out_proj.weight"), W, vp(e, p + "self_attn.out_proj.bias"), 0, x, xn);
     std::swap(x, xn);

@@ -194,6 +194,21 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
     for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int frow = lane & 15, fq = lane >> 4;
 
+  // LayerNorm folded into this GEMM: (rstd, rstd * mean) of the tile's rows from the producer's per-strip partials, summed by
+  // the MFMA waves of column 0 while the first K-step is in flight (they would wait on the first barrier otherwise) and parked
+  // in LDS behind the ring; the epilogue reads two floats per row instead of re-summing up to N/32 partials per lane.
+  float2* lnsm = reinterpret_cast<float2*>(smem + STAGES * STAGE);
+  const bool ln_lds = p.ln_stats != nullptr && p.splitk == 1;
+  if (ln_lds && wn == 0) {
+    for (int rr = lane; rr < TM; rr += 64) {
+      const int m = m0 + wm * TM + rr;
+      float r = 0.f, rm = 0.f;
+      if (m < p.M) ln_row_scalars(p, m, r, rm);
+      lnsm[wm * TM + rr] = make_float2(r, rm);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // written before this wave's next barrier, read after the pre-epilogue one
+  }
+
   // the bias is needed only by the epilogue: fetch it now (issued before, hence older than, every DMA) so the
   // epilogue does not start with a dependent global round trip
   f32x4 bpre[NI];
@@ -333,7 +348,8 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
   stamp(p, 3);
   if (dbg_on(p, 32)) return;
   static_assert(4 * epilogue_scratch_bytes(TN) <= STAGES * STAGE, "epilogue scratch");
-  epilogue<NI, MI, TM, TN>(p, acc, m0, n0, wm, wn, frow, fq, z, bpre, use_bpre, smem + wave * epilogue_scratch_bytes(TN));
+  epilogue<NI, MI, TM, TN>(p, acc, m0, n0, wm, wn, frow, fq, z, bpre, use_bpre, smem + wave * epilogue_scratch_bytes(TN),
+                           ln_lds ? lnsm + wm * TM : nullptr);
   if (dbg_on(p, 64)) {
     stamp(p, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -526,6 +542,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KP p) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) v += t[u];
   }
+  if (p.ln_stats) {                 // LayerNorm folded into the GEMM: see KP::ln_stats
+    float r, rm;
+    ln_row_scalars(p, m, r, rm);
+    v = v * r - *reinterpret_cast<const f32x4*>(p.ln_s + n) * rm;
+  }
   v += bv;
   v += b2;
   if (p.act == 1) {
@@ -677,6 +698,14 @@ static Plan make_plan(const ConvGemm& p) {
   return best;
 }
 
+// columns per epilogue strip of a plan: the wave tile width of the implicit-GEMM kernels, the whole tile of the halo kernel
+static int plan_tn(const Plan& pl) { return kTiles[pl.tile].kind == TK_HALO ? kTiles[pl.tile].bn : kTiles[pl.tile].bn / 2; }
+
+int conv_gemm_stats_strips(const ConvGemm& p) {
+  const Plan pl = make_plan(p);
+  return pl.splitk == 1 ? cdiv(p.N, plan_tn(pl)) : 0;
+}
+
 size_t conv_gemm_workspace_bytes(const ConvGemm& p) {
   const Plan pl = make_plan(p);
   return pl.splitk > 1 ? (size_t)pl.splitk * p.M * p.N * sizeof(float) : 0;
@@ -705,7 +734,7 @@ static bool use_ws() {
 template <int BM, int BN, int ST>
 static int launch_dma(int ups, const KP& kp, int tiles, hipStream_t stream) {
   static bool done[4] = {false, false, false, false};
-  constexpr int smem = ST * (BM + BN) * 128;
+  constexpr int smem = ST * (BM + BN) * 128 + BM * 8;      // ring + the LayerNorm row scalars (conv_gemm_dma_kernel: lnsm)
   if (use_ws())
     return ups ? launch_k(&conv_gemm_dma_kernel<BM, BN, ST, true, true>, smem, &done[3], kp, tiles, stream, 512)
                : launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, true>, smem, &done[2], kp, tiles, stream, 512);
@@ -746,6 +775,18 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
   kp.ups = p.ups; kp.HoWo = p.Ho * p.Wo;
   kp.ldx = p.ldx; kp.ldw = p.ldw; kp.ldy = p.ldy; kp.ldres = p.ldres; kp.ld_bias2 = p.ld_bias2;
   kp.act = p.act; kp.bias_per_row = p.bias_per_row; kp.scale = p.scale;
+  if (p.ln_stats) {
+    SDEO_CHECK(p.ln_s && p.ln_strips >= 1 && p.ln_ld >= p.ln_strips && p.ln_c > 0, "conv_gemm: incomplete LayerNorm-fold arguments");
+    SDEO_CHECK(!p.bias_per_row && !p.y32, "conv_gemm: the LayerNorm fold applies to row-major fp16 products only");
+    kp.ln_stats = p.ln_stats; kp.ln_s = p.ln_s; kp.ln_strips = p.ln_strips; kp.ln_ld = p.ln_ld;
+    kp.ln_invc = 1.0f / (float)p.ln_c; kp.ln_eps = p.ln_eps;
+  }
+  if (p.stats_out) {
+    const int strips = pl.splitk == 1 ? cdiv(p.N, plan_tn(pl)) : 0;
+    SDEO_CHECK(strips >= 1 && p.stats_ld >= strips && p.y && !p.y32 && p.act != 3,
+               "conv_gemm: row statistics need an unsplit fp16 plan (strips %d, stats_ld %d)", strips, p.stats_ld);
+    kp.stats_out = p.stats_out; kp.stats_ld = p.stats_ld;
+  }
   kp.nk = pl.nk; kp.splitk = pl.splitk; kp.nk_per_split = cdiv(pl.nk, pl.splitk);
   kp.tiles_m = pl.tiles_m; kp.tiles_n = pl.tiles_n;
   {

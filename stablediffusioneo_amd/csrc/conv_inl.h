@@ -30,6 +30,17 @@ struct KP {
   int dbg;
   int n_fastest;     // tile order inside an XCD's contiguous run: 1 = all N tiles of an M tile are neighbours
   int coalesce;      // host-checked: the LDS-transposed 16-byte epilogue applies (see epilogue_rows)
+  // ---- LayerNorm folded into this GEMM (the consumer of a pre-LN residual stream, `attention.py:381-385`):
+  //      LN(x) W^T + b = rstd * (x W'^T - mean * s) + b'   with W' = W * gamma (fp16), s[n] = sum_k W'[n][k],
+  //      b'[n] = b[n] + sum_k beta[k] W[n][k] (passed as `bias`).  The K loop runs on the RAW x; the epilogue applies the two
+  //      per-row scalars.  (mean, rstd) come from per-row partial (sum, sum of squares) written by the PRODUCER of x.
+  const float* ln_stats;   // [rows][ln_ld][2] partial (sum, sumsq) per row of x, ln_strips valid partials per row; null = off
+  const float* ln_s;       // [N]
+  int ln_strips, ln_ld;
+  float ln_invc, ln_eps;
+  // ---- producer side: per-row partial (sum, sumsq) of the values this launch stores, one partial per TN-wide strip
+  float* stats_out;        // [M][stats_ld][2]; null = off
+  int stats_ld;
 };
 
 // Ablation / stamp switches exist only in the measurement build: in the production library dbg_on() is the constant false and
@@ -75,7 +86,7 @@ __device__ __forceinline__ int swz_chunk(int row, int chunk) {
 // wave transposes each 16-row block of fp32 results through LDS so that every lane then moves 8 consecutive channels:
 // 16-byte residual loads and 16-byte stores in runs of TN*2 contiguous bytes per row, instead of 8-byte pieces in 32-byte
 // runs (measured: the 8-byte epilogue took ~4 us of a 24 us conv).  Same arithmetic, same single rounding.
-constexpr int epilogue_scratch_bytes(int tn) { return 16 * (tn * 4 + 16); }
+constexpr int epilogue_scratch_bytes(int tn) { return 16 * (tn * 4 + 16) + 16 * tn; }   // + [16 rows][tn / 8] float2 row-statistics partials
 
 // one 16-row block of the coalesced epilogue, flags resolved at compile time (a scalar branch per flag per tile cost more
 // than the arithmetic: ~60 taken branches per wave)
@@ -107,9 +118,52 @@ __device__ __forceinline__ void stage_block(const KP& p, const f32x4 (&accj)[NI]
   }
 }
 
+// (mean, rstd) of one row of the LayerNorm'ed operand from the producer's per-strip partials (fixed order: deterministic)
+__device__ __forceinline__ void ln_row_scalars(const KP& p, int row, float& r, float& rm) {
+  const float2* src = reinterpret_cast<const float2*>(p.ln_stats) + (size_t)row * p.ln_ld;
+  float s = 0.f, q = 0.f;
+  for (int t0 = 0; t0 < p.ln_strips; t0 += 8) {       // 8 independent loads in flight, summed in a fixed order
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = t0 + u < p.ln_strips ? src[t0 + u] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s += v[u].x; q += v[u].y; }
+  }
+  const float mean = s * p.ln_invc;
+  float var = q * p.ln_invc - mean * mean;
+  var = var < 0.f ? 0.f : var;
+  r = rsqrtf(var + p.ln_eps);
+  rm = r * mean;
+}
+
+// acc <- rstd * acc - rstd * mean * s   (see KP::ln_stats).  `lnrow` (optional, LDS): the (rstd, rstd * mean) of this wave's
+// rows, indexed j * 16 + frow, computed at kernel start while the first K-step was in flight (conv_gemm_dma_kernel); without it
+// each lane sums its rows' partials here.
+template <int NI, int MI>
+__device__ __forceinline__ void ln_correct(const KP& p, f32x4 (&acc)[NI][MI], const int (&mrow)[MI], int nb, int fq,
+                                           const float2* lnrow) {
+  const int frow = threadIdx.x & 15;
+  float r[MI], rm[MI];
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    r[j] = 0.f; rm[j] = 0.f;
+    if (lnrow) { const float2 v = lnrow[j * 16 + frow]; r[j] = v.x; rm[j] = v.y; }
+    else if (mrow[j] >= 0) ln_row_scalars(p, mrow[j], r[j], rm[j]);
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int n = nb + i * 16 + fq * 4;
+    const f32x4 sv = n < p.N ? *reinterpret_cast<const f32x4*>(p.ln_s + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[i][j] = acc[i][j] * r[j] - sv * rm[j];
+  }
+}
+
 template <int NI, int MI, int TN>
 __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI], const int (&mrow)[MI], int nb, int fq, int z,
-                                              const f32x4 (&bpre)[NI], bool use_bpre, char* scratch = nullptr) {
+                                              const f32x4 (&bpre)[NI], bool use_bpre, char* scratch = nullptr,
+                                              const float2* lnrow = nullptr) {
+  if (p.ln_stats && p.splitk == 1) ln_correct<NI, MI>(p, acc, mrow, nb, fq, lnrow);
   if (scratch && p.coalesce) {
     constexpr int ROWB = TN * 4 + 16;            // odd multiple of 16 bytes: the 16 rows of a block start in different banks
     constexpr int G = TN / 8;                    // 8-channel groups per row
@@ -161,18 +215,36 @@ __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI],
         default: stage_block<NI, TN, true, 2>(p, accj, bias, m, nb, fq, frow, scratch); break;
       }
       __builtin_amdgcn_wave_barrier();
+      float2* spart = reinterpret_cast<float2*>(scratch + 16 * ROWB);     // [16 rows][G] partial (sum, sumsq) of the stored values
 #pragma unroll
       for (int t = 0; t < PASSES; ++t) {
-        if (mm[t] < 0) continue;
-        const char* src = scratch + rr[t] * ROWB + (nn[t] - nb) * 4;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 16);
-        f16x8 o;
+        float ssum = 0.f, ssq = 0.f;
+        if (mm[t] >= 0) {
+          const char* src = scratch + rr[t] * ROWB + (nn[t] - nb) * 4;
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 16);
+          f16x8 o;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          o[u] = (f16)(lo[u] + (float)resv[t][u]);
-          o[4 + u] = (f16)(hi[u] + (float)resv[t][4 + u]);
+          for (int u = 0; u < 4; ++u) {
+            o[u] = (f16)(lo[u] + (float)resv[t][u]);
+            o[4 + u] = (f16)(hi[u] + (float)resv[t][4 + u]);
+          }
+          *reinterpret_cast<f16x8*>(p.y + (size_t)mm[t] * p.ldy + nn[t]) = o;
+          if (p.stats_out) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const float f = (float)o[u]; ssum += f; ssq += f * f; }
+          }
         }
-        *reinterpret_cast<f16x8*>(p.y + (size_t)mm[t] * p.ldy + nn[t]) = o;
+        if (p.stats_out && t * 64 + lane < 16 * G) spart[t * 64 + lane] = make_float2(ssum, ssq);     // index = row * G + group
+      }
+      if (p.stats_out) {
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 16 && m >= 0 && nb < p.N) {   // lanes 0..15 have fq == 0 and frow == lane: `m` is the row index of block row `lane`;
+                                                 // a strip wholly past N (tile padding) has no slot in the statistics row
+          float ts = 0.f, tq = 0.f;
+#pragma unroll
+          for (int g = 0; g < G; ++g) { const float2 v = spart[lane * G + g]; ts += v.x; tq += v.y; }
+          reinterpret_cast<float2*>(p.stats_out)[(size_t)m * p.stats_ld + nb / TN] = make_float2(ts, tq);
+        }
       }
       __builtin_amdgcn_wave_barrier();        // the next block overwrites the scratch rows
     }
@@ -205,6 +277,7 @@ __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI],
       }
     }
     const int b = p.bias2 ? m / p.HoWo : 0;
+    float ssum = 0.f, ssq = 0.f;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int n = nb + i * 16 + fq * 4;
@@ -240,7 +313,17 @@ __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI],
 #pragma unroll
         for (int t = 0; t < 4; ++t) o[t] = (f16)v[t];
         *reinterpret_cast<f16x4*>(p.y + (size_t)m * p.ldy + n) = o;
+        if (p.stats_out) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { const float f = (float)o[t]; ssum += f; ssq += f * f; }
+        }
       }
+    }
+    if (p.stats_out && p.splitk == 1) {
+      // the four lanes fq = 0..3 with this frow hold the strip's columns of row m between them
+      ssum += __shfl_xor(ssum, 16, 64); ssq += __shfl_xor(ssq, 16, 64);
+      ssum += __shfl_xor(ssum, 32, 64); ssq += __shfl_xor(ssq, 32, 64);
+      if (fq == 0 && nb < p.N) reinterpret_cast<float2*>(p.stats_out)[(size_t)m * p.stats_ld + nb / TN] = make_float2(ssum, ssq);
     }
   }
 }
@@ -248,14 +331,15 @@ __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI],
 // implicit-GEMM tiles: accumulator tile (i, j) of wave (wm, wn) is output row m0 + wm*TM + j*16 + frow
 template <int NI, int MI, int TM, int TN>
 __device__ __forceinline__ void epilogue(const KP& p, f32x4 (&acc)[NI][MI], int m0, int n0, int wm, int wn, int frow, int fq, int z,
-                                         const f32x4 (&bpre)[NI], bool use_bpre, char* scratch = nullptr) {
+                                         const f32x4 (&bpre)[NI], bool use_bpre, char* scratch = nullptr,
+                                         const float2* lnrow = nullptr) {
   int mrow[MI];
 #pragma unroll
   for (int j = 0; j < MI; ++j) {
     const int m = m0 + wm * TM + j * 16 + frow;
     mrow[j] = m < p.M ? m : -1;
   }
-  epilogue_rows<NI, MI, TN>(p, acc, mrow, n0 + wn * TN, fq, z, bpre, use_bpre, scratch);
+  epilogue_rows<NI, MI, TN>(p, acc, mrow, n0 + wn * TN, fq, z, bpre, use_bpre, scratch, lnrow);
 }
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (observed, speed only), so give each

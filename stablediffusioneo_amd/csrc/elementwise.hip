@@ -342,4 +342,74 @@ int embed_tokens(f16* out, const int32_t* ids, const f16* tok_emb, const f16* po
   return 0;
 }
 
+// ---- LayerNorm folded into the following Linear (conv_inl.h, KP::ln_stats): one wave per output row r
+//      w_out[r][k] = fp16(w[r][k] * gamma[k]);  s[r] = sum_k w_out[r][k];  b_out[r] = bias[r] + sum_k beta[k] * w[r][k]
+__global__ __launch_bounds__(256) void fold_layernorm_kernel(f16* __restrict__ w_out, float* __restrict__ s_out,
+                                                             float* __restrict__ b_out, const f16* __restrict__ w,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ bias, int rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float ss = 0.f, sb = 0.f;
+  for (int k = lane * 8; k < C; k += 64 * 8) {
+    const f16x8 wv = *reinterpret_cast<const f16x8*>(w + (size_t)r * C + k);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float wf = (float)wv[j];
+      o[j] = (f16)(wf * gamma[k + j]);
+      ss += (float)o[j];
+      sb += wf * beta[k + j];
+    }
+    *reinterpret_cast<f16x8*>(w_out + (size_t)r * C + k) = o;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    ss += __shfl_xor(ss, off, 64);
+    sb += __shfl_xor(sb, off, 64);
+  }
+  if (lane == 0) {
+    s_out[r] = ss;
+    b_out[r] = sb + (bias ? bias[r] : 0.f);
+  }
+}
+
+int fold_layernorm(f16* w_out, float* s_out, float* b_out, const f16* w, const float* gamma, const float* beta,
+                   const float* bias, int rows, int C, hipStream_t stream) {
+  SDEO_CHECK(w_out && s_out && b_out && w && gamma && beta && rows > 0 && C > 0 && C % 8 == 0, "fold_layernorm: bad operand");
+  hipLaunchKernelGGL(fold_layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, w_out, s_out, b_out, w, gamma, beta, bias,
+                     rows, C);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+// per-row (sum, sum of squares) of [rows][C] fp16 as ONE partial per row: stats[r][ld][2] (fallback producer of the
+// LayerNorm statistics when the GEMM that wrote x ran split-K)
+__global__ __launch_bounds__(256) void row_stats_kernel(float* __restrict__ stats, int ld, const f16* __restrict__ x, int ldx,
+                                                        int rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float s = 0.f, q = 0.f;
+  for (int k = lane * 8; k < C; k += 64 * 8) {
+    const f16x8 v = *reinterpret_cast<const f16x8*>(x + (size_t)r * ldx + k);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s += f; q += f * f; }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    s += __shfl_xor(s, off, 64);
+    q += __shfl_xor(q, off, 64);
+  }
+  if (lane == 0) reinterpret_cast<float2*>(stats)[(size_t)r * ld] = make_float2(s, q);
+}
+
+int row_stats(float* stats, int ld, const f16* x, int ldx, int rows, int C, hipStream_t stream) {
+  SDEO_CHECK(stats && x && rows > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ld >= 1, "row_stats: bad operand");
+  hipLaunchKernelGGL(row_stats_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, stats, ld, x, ldx, rows, C);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace sdeo

@@ -33,8 +33,20 @@ struct ConvGemm {
   float scale = 1.0f;
   int force_tile = -1;         // testing hook: tile config index
   int force_splitk = 0;
+  // LayerNorm folded into the GEMM (see KP::ln_stats in conv_inl.h): x is used raw, w = W * gamma, bias = b + W beta,
+  // ln_s[n] = sum_k w[n][k]; ln_stats = the per-row partial (sum, sumsq) the producer of x emitted (ln_strips valid of ln_ld)
+  const float* ln_stats = nullptr;
+  const float* ln_s = nullptr;
+  int ln_strips = 0, ln_ld = 0;
+  int ln_c = 0;                // channels normalised over (= K for rows mode)
+  float ln_eps = 1e-5f;
+  // emit per-row partial (sum, sumsq) of the stored fp16 values: stats_out[m][stats_ld][2], conv_gemm_stats_strips(p) valid
+  float* stats_out = nullptr;
+  int stats_ld = 0;
 };
 int conv_gemm(const ConvGemm& p, hipStream_t stream);
+// strips (partials per row) a launch of p writes to stats_out; 0 when the chosen plan cannot emit them (split-K)
+int conv_gemm_stats_strips(const ConvGemm& p);
 // measurement only: phase stamps of the last launch of an implicit-GEMM / halo kernel (SDEO_DBG_GEMM bit 6), see conv_inl.h
 int conv_gemm_read_stamps(unsigned long long* out, int n);
 int conv_halo_read_stamps(unsigned long long* out, int n);
@@ -63,13 +75,13 @@ int layernorm(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const 
 
 // ------------------------------------------------------------------------------------------
 // Fused attention  O = softmax(Q K^T * scale) V   (flash-style, scores never materialised)
-//   Q[(b*Tq+t)*ldq + h*d + i], K[(b*TkS+j)*ldk + h*d + i], Vt[(h*d+i)*ldvt + b*TkSv + j]
-//   O[(b*Tq+t)*ldo + h*d + i];  keys j >= Tk are masked;  TkS / TkSv = per-batch strides of K rows / V^T columns.
+//   Q[(b*Tq+t)*ldq + h*d + i], K[(b*TkS+j)*ldk + h*d + i], V[(b*TkSv+j)*ldv + h*d + i]   (all row-major)
+//   O[(b*Tq+t)*ldo + h*d + i];  keys j >= Tk are masked;  TkS / TkSv = per-batch row strides of K / V.
 //   causal: key j additionally masked for query t when j > t (needs Tq == Tk).
 // ------------------------------------------------------------------------------------------
-int attention(f16* o, int ldo, const f16* q, int ldq, const f16* k, int ldk, const f16* vt, int ldvt, int B, int H,
+int attention(f16* o, int ldo, const f16* q, int ldq, const f16* k, int ldk, const f16* v, int ldv, int B, int H,
               int Tq, int Tk, int TkS, int TkSv, int d, float scale, hipStream_t stream, int causal = 0);
-// vt[c][b*TkSv + t] = v[(b*T + t)*ldv + c]   (fallback when T is too small for the transposed GEMM)
+// vt[c][b*TkSv + t] = v[(b*T + t)*ldv + c]   (VAE AttnBlock's materialised-score path)
 int transpose_pad(f16* vt, int ldvt, const f16* v, int ldv, int B, int T, int TkSv, int C, hipStream_t stream);
 
 // row softmax: fp32 scores [rows][ld] -> fp16 probabilities (VAE single-head attention)
@@ -100,6 +112,11 @@ int f16_to_f32(float* y, const f16* x, int64_t n, hipStream_t stream);
 // GEGLU projection [2H][cols] fp32 -> fp16 with value / gate rows interleaved in blocks of 16 (see conv_gemm act = 3); bias variant
 int geglu_interleave_f32_to_f16(f16* y, const float* x, int H, int cols, hipStream_t stream);
 int geglu_interleave_f32(float* y, const float* x, int H, hipStream_t stream);
+// LayerNorm folded into a Linear (KP::ln_stats): w_out = fp16(w * gamma), s = row sums of w_out, b_out = bias + w beta
+int fold_layernorm(f16* w_out, float* s_out, float* b_out, const f16* w, const float* gamma, const float* beta,
+                   const float* bias, int rows, int C, hipStream_t stream);
+// stats[r][ld][2] <- one (sum, sumsq) partial per row of x [rows][C]
+int row_stats(float* stats, int ld, const f16* x, int ldx, int rows, int C, hipStream_t stream);
 // CLIP text embeddings: out[(b*T + t)][0:W] = tok_emb[ids[b*T + t]][0:W] + pos_emb[t][0:W]   (ids are clamped to [0, vocab))
 int embed_tokens(f16* out, const int32_t* ids, const f16* tok_emb, const f16* pos_emb, int B, int T, int W, int vocab,
                  hipStream_t stream);

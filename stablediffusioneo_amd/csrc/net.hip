@@ -14,8 +14,11 @@
 //     control scale are epilogues of the producing conv/GEMM;
 //   * nearest-x2 Upsample is folded into the following conv's gather; channel concat is a write into place;
 //   * every ResBlock's emb_layers Linear is one stacked GEMM per forward (same input SiLU(emb));
-//   * q and k projections of self-attention are one GEMM; V is produced transposed by a GEMM with swapped
-//     operands so the attention kernel needs no transpose;
+//   * q, k and v projections of self-attention are ONE GEMM (the attention kernel reads V row-major through transposing
+//     LDS reads), cross-attention K and V likewise;
+//   * every LayerNorm of a BasicTransformerBlock is folded into the GEMM that consumes it (gamma into the weights at load
+//     time, mean / rstd as two per-row scalars in the epilogue); the per-row statistics are written by the epilogue of the
+//     GEMM that produced the residual stream, so no LayerNorm kernel and no normalised copy of the tokens exists;
 //   * cross-attention K / V^T depend only on the text context and the hint block only on the hint: both are
 //     computed once per image and cached across the DDIM steps.
 #include <functional>
@@ -195,6 +198,9 @@ typedef std::vector<Op> Program;
 
 struct ProfRec { std::string key; double flops, bytes; hipEvent_t a, b; };
 
+// LayerNorm folded into a Linear at weight-finalisation time (fold_layernorm): offsets into the weight slab
+struct FoldJob { size_t w_out, s_out, b_out, w_in; std::string gamma, beta, bias; int rows, C; };
+
 }  // namespace
 
 struct sdeo_handle_s {
@@ -204,7 +210,8 @@ struct sdeo_handle_s {
   // weights
   std::vector<WEntry> weights;
   std::unordered_map<std::string, int> windex;
-  std::unordered_map<std::string, size_t> named_off;   // extra named regions (stacked parents)
+  std::unordered_map<std::string, size_t> named_off;   // extra named regions (stacked parents, LayerNorm-folded copies)
+  std::vector<FoldJob> folds;
   char* wslab = nullptr;
   size_t wslab_bytes = 0;
   float* stage = nullptr;
@@ -311,20 +318,38 @@ static void reg_attn(Registry& r, const std::string& ns, const Blk& b, int ctx) 
   r.norm(p + ".norm", c);
   r.conv(p + ".proj_in", c, c, 1);
   const std::string t = p + ".transformer_blocks.0";
-  // attn1: to_q and to_k stacked as one [2c][c] matrix
-  const size_t qk = r.take((size_t)2 * c * c * 2);
-  r.e->named_off[t + ".attn1.to_qk"] = qk;
-  r.add(t + ".attn1.to_q.weight", W_LINEAR, {c, c}, qk);
-  r.add(t + ".attn1.to_k.weight", W_LINEAR, {c, c}, qk + (size_t)c * c * 2);
-  r.lin(t + ".attn1.to_v", c, c, false);
+  // attn1: to_q, to_k, to_v stacked as one [3c][c] matrix (raw); the copy the network runs on has norm1 folded in
+  const size_t qkv = r.take((size_t)3 * c * c * 2);
+  r.add(t + ".attn1.to_q.weight", W_LINEAR, {c, c}, qkv);
+  r.add(t + ".attn1.to_k.weight", W_LINEAR, {c, c}, qkv + (size_t)c * c * 2);
+  r.add(t + ".attn1.to_v.weight", W_LINEAR, {c, c}, qkv + (size_t)2 * c * c * 2);
   r.lin(t + ".attn1.to_out.0", c, c, true);
   r.lin(t + ".attn2.to_q", c, c, false);
-  r.lin(t + ".attn2.to_k", ctx, c, false);
-  r.lin(t + ".attn2.to_v", ctx, c, false);
+  // attn2: to_k and to_v stacked as one [2c][ctx] matrix (one GEMM per context)
+  const size_t kv = r.take((size_t)2 * c * ctx * 2);
+  r.e->named_off[t + ".attn2.to_kv"] = kv;
+  r.add(t + ".attn2.to_k.weight", W_LINEAR, {c, ctx}, kv);
+  r.add(t + ".attn2.to_v.weight", W_LINEAR, {c, ctx}, kv + (size_t)c * ctx * 2);
   r.lin(t + ".attn2.to_out.0", c, c, true);
-  r.add(t + ".ff.net.0.proj.weight", W_GEGLU_W, {8 * c, c}, r.take((size_t)8 * c * c * 2));
+  const size_t ff1 = r.take((size_t)8 * c * c * 2);
+  r.add(t + ".ff.net.0.proj.weight", W_GEGLU_W, {8 * c, c}, ff1);
   r.add(t + ".ff.net.0.proj.bias", W_GEGLU_B, {8 * c}, r.take((size_t)8 * c * 4));
   r.lin(t + ".ff.net.2", 4 * c, c, true);
+  // LayerNorm-folded copies (built by sdeo_finalize_weights): weights, row sums s, bias'
+  auto fold = [&](const std::string& name, size_t w_in, int rows, const std::string& norm, const std::string& bias) {
+    FoldJob f;
+    f.w_out = r.take((size_t)rows * c * 2);
+    f.s_out = r.take((size_t)rows * 4);
+    f.b_out = r.take((size_t)rows * 4);
+    f.w_in = w_in; f.gamma = norm + ".weight"; f.beta = norm + ".bias"; f.bias = bias; f.rows = rows; f.C = c;
+    r.e->named_off[name + ".w"] = f.w_out;
+    r.e->named_off[name + ".s"] = f.s_out;
+    r.e->named_off[name + ".b"] = f.b_out;
+    r.e->folds.push_back(f);
+  };
+  fold(t + ".attn1.qkv_ln", qkv, 3 * c, t + ".norm1", "");
+  fold(t + ".attn2.q_ln", r.e->weights[r.e->windex.at(t + ".attn2.to_q.weight")].off, c, t + ".norm2", "");
+  fold(t + ".ff1_ln", ff1, 8 * c, t + ".norm3", t + ".ff.net.0.proj.bias");
   r.norm(t + ".norm1", c);
   r.norm(t + ".norm2", c);
   r.norm(t + ".norm3", c);
@@ -429,6 +454,11 @@ static void build_registry(Engine* e) {
 // ------------------------------------------------------------------------------------------------
 // program builder
 // ------------------------------------------------------------------------------------------------
+struct RowStats {                     // per-row (sum, sumsq) partials of a [rows][c] tensor: fp32 [rows][ld][2]
+  float* p = nullptr;
+  int ld = 0, strips = 0, c = 0;
+};
+
 struct ConvOpts {                     // conv / gemm options
   const float* bias2 = nullptr; int ld_bias2 = 0;
   const T* res = nullptr;
@@ -436,6 +466,9 @@ struct ConvOpts {                     // conv / gemm options
   const float* scale_host = nullptr;   // read at launch time (control scales)
   const T* out = nullptr;        // write into this view instead of allocating
   int cout_store = -1;           // stored output channels (>= logical, padded rows of W are zero)
+  RowStats* stats = nullptr;     // producer: emit per-row (sum, sumsq) partials of the stored values into this buffer
+  const RowStats* ln = nullptr;  // consumer: LayerNorm folded into this GEMM, statistics of x from *ln, row sums ln_s
+  const float* ln_s = nullptr;
 };
 
 struct Builder {
@@ -477,7 +510,7 @@ struct Builder {
   const float* named_v(const std::string& name) { return reinterpret_cast<const float*>(e->wslab + e->named_off.at(name)); }
 
 
-  void launch_conv(ConvGemm p, const float* scale_host) {
+  void launch_conv(ConvGemm p, const float* scale_host, RowStats* stats = nullptr) {
     max_splitk = std::max(max_splitk, e->autotune ? conv_gemm_autotune_workspace_bytes(p) : conv_gemm_workspace_bytes(p));
     if (!dry && e->autotune) {
       ConvGemm q = p;
@@ -488,6 +521,14 @@ struct Builder {
     if (!dry && getenv("SDEO_DUMP_GEMM"))   // shape census for tools/tune_gemm.py
       fprintf(stderr, "SDEO_GEMM %d %d %d %d %d %d %d %d %d %d %s\n", p.M, p.N, p.K, p.Cin, p.R, p.stride, p.ups, p.B, p.Hi, p.Wi,
               conv_gemm_kernel_name(p));
+    bool stats_by_kernel = false;
+    if (stats) {
+      // the epilogue of an unsplit plan writes one partial per strip; a split-K plan leaves them to a row_stats launch
+      stats->c = p.N;
+      stats->strips = conv_gemm_stats_strips(p);
+      if (stats->strips > 0 && stats->strips <= stats->ld) { p.stats_out = stats->p; p.stats_ld = stats->ld; }
+      else { stats->strips = 1; stats_by_kernel = true; }
+    }
     Engine* eng = e;
     const int sel = ws_sel;
     push([p, scale_host, eng, sel](hipStream_t s) mutable {
@@ -499,6 +540,31 @@ struct Builder {
        2.0 * ((double)p.M * p.Cin * (p.R * p.S > 1 ? 1 : 1) + (double)p.N * p.K + (double)p.M * p.N),
        "M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) + " R" + std::to_string(p.R) + " s" +
            std::to_string(p.stride) + " u" + std::to_string(p.ups));
+    if (stats_by_kernel) {
+      float* sp = stats->p; const int ld = stats->ld, rows = p.M, C = p.N, ldy = p.ldy; const f16* y = p.y;
+      push([=](hipStream_t s) { return row_stats(sp, ld, y, ldy, rows, C, s); }, "row_stats", 0, 2.0 * rows * C,
+           "rows" + std::to_string(rows) + " C" + std::to_string(C));
+    }
+  }
+
+  RowStats alloc_stats(int rows, int c) {
+    RowStats st;
+    st.ld = std::max(1, (c + 31) / 32);          // narrowest epilogue strip is 32 columns
+    st.c = c;
+    T raw = alloc2d(rows, st.ld * 4);            // rows * ld * 2 floats in an fp16-typed arena block
+    st.p = reinterpret_cast<float*>(raw.p);
+    stats_blocks.push_back(raw);
+    return st;
+  }
+  void release_stats() {                         // statistics buffers live until the end of their transformer block
+    for (auto& t : stats_blocks) release(t);
+    stats_blocks.clear();
+  }
+  std::vector<T> stats_blocks;
+
+  static void set_ln(ConvGemm& p, const ConvOpts& o) {
+    if (!o.ln) return;
+    p.ln_stats = o.ln->p; p.ln_s = o.ln_s; p.ln_strips = o.ln->strips; p.ln_ld = o.ln->ld; p.ln_c = o.ln->c; p.ln_eps = 1e-5f;
   }
 
   // conv on an image view; weights by name (".weight"/".bias" appended)
@@ -517,7 +583,7 @@ struct Builder {
     p.B = x.n; p.Hi = x.h; p.Wi = x.w; p.Cin = x.c; p.Ho = ho; p.Wo = wo; p.R = p.S = k; p.stride = stride; p.pad = pad; p.ups = ups;
     p.M = x.n * ho * wo; p.N = cs; p.K = k * k * x.c;
     p.ldx = x.ld; p.ldw = p.K; p.ldy = y.ld; p.act = o.act;
-    launch_conv(p, o.scale_host);
+    launch_conv(p, o.scale_host, o.stats);
     T r = y;
     if (o.out) r.off = (size_t)-1;
     return r;
@@ -534,7 +600,9 @@ struct Builder {
     if (o.res) { p.res = o.res->p; p.ldres = o.res->ld; }
     p.B = rows; p.Cin = x.c; p.M = rows; p.N = n; p.K = x.c;
     p.ldx = x.ld; p.ldw = ldw; p.act = o.act;
-    launch_conv(p, o.scale_host);
+    set_ln(p, o);
+    if (o.ln && o.ln->c != x.c && err.empty()) err = "LayerNorm statistics of a " + std::to_string(o.ln->c) + "-channel tensor fed to K = " + std::to_string(x.c);
+    launch_conv(p, o.scale_host, o.stats);
     if (o.out) y.off = (size_t)-1;
     return y;
   }
@@ -576,10 +644,10 @@ struct Builder {
     return y;
   }
 
-  void attn(const T& o, const f16* q, int ldq, const f16* k, int ldk, const f16* vt, int ldvt, int B, int H, int Tq, int Tk, int TkS, int TkSv, int d) {
+  void attn(const T& o, const f16* q, int ldq, const f16* k, int ldk, const f16* v, int ldv, int B, int H, int Tq, int Tk, int TkS, int TkSv, int d) {
     f16* op = o.p; const int ldo = o.ld;
     const float scale = 1.0f / sqrtf((float)d);
-    push([=](hipStream_t s) { return attention(op, ldo, q, ldq, k, ldk, vt, ldvt, B, H, Tq, Tk, TkS, TkSv, d, scale, s); }, "attention",
+    push([=](hipStream_t s) { return attention(op, ldo, q, ldq, k, ldk, v, ldv, B, H, Tq, Tk, TkS, TkSv, d, scale, s); }, "attention",
          4.0 * B * H * (double)Tq * Tk * d, 2.0 * B * H * d * (2.0 * Tq + 2.0 * Tk),
          "Tq" + std::to_string(Tq) + " Tk" + std::to_string(Tk) + " d" + std::to_string(d));
   }
@@ -611,9 +679,11 @@ static T build_res(Builder& b, const std::string& ns, const Blk& blk, const T& x
   return y;
 }
 
-struct CtxKV { T k, vt; };   // cross-attention K [N*TkS][C] and V^T [C][N*TkS]
+struct CtxKV { T kv; };   // cross-attention K | V of one attention block: [N*TkS][2C] (K in columns 0..C-1, V in C..2C-1)
 
-// SpatialTransformer.forward + BasicTransformerBlock._forward (`attention.py:381-385,431-450`)
+// SpatialTransformer.forward + BasicTransformerBlock._forward (`attention.py:381-385,431-450`).  Each pre-LN sub-block
+// x + f(LN(x)) runs as: [GEMM that writes x also writes x's per-row statistics] -> [GEMM of f's first Linear on the RAW x with
+// LN folded in] -> ... ; see the file comment.
 static T build_attn(Builder& b, const std::string& ns, const Blk& blk, const T& x, const CtxKV& kv, const T* out = nullptr) {
   const sdeo_config& c = b.e->cfg;
   const std::string p = ns + blk.name;
@@ -621,56 +691,41 @@ static T build_attn(Builder& b, const std::string& ns, const Blk& blk, const T& 
   const int C = blk.cin, H = c.num_heads, d = C / H, N = x.n, Tq = x.h * x.w;
   const int TkS = round8(c.context_len);
   T g = b.gn(x, p + ".norm", 1e-6f, 0);
-  T tok = b.conv(g, p + ".proj_in", C, 1, 1, 0);
+  RowStats st0 = b.alloc_stats(x.rows(), C), st1 = b.alloc_stats(x.rows(), C), st2 = b.alloc_stats(x.rows(), C);
+  Builder::CO pi; pi.stats = &st0;
+  T tok = b.conv(g, p + ".proj_in", C, 1, 1, 0, pi);
   b.release(g);
-  // attn1 (self)
-  T a = b.ln(tok, t + ".norm1");
-  T qk = b.gemm(a, b.named_w(t + ".attn1.to_qk"), C, 2 * C, nullptr);
-  T vt;
-  int TqS = Tq;
-  if (Tq % 8 == 0) {
-    vt = b.gemm_t(a, b.wptr(t + ".attn1.to_v.weight"), C, C, nullptr);
-  } else {   // tiny token counts (latent < 8 px at this level): V by the plain GEMM, then a padded transpose
-    TqS = round8(Tq);
-    T v = b.gemm(a, b.wptr(t + ".attn1.to_v.weight"), C, C, nullptr);
-    vt = b.alloc2d(C, N * TqS);
-    f16* vp = vt.p; const f16* sp = v.p; const int ldv = v.ld, ldvt = N * TqS;
-    b.push([=](hipStream_t s) { return transpose_pad(vp, ldvt, sp, ldv, N, Tq, TqS, C, s); });
-    b.release(v);
-  }
-  b.release(a);
+  // attn1 (self): q | k | v = LN1(tok) [Wq; Wk; Wv]^T in one GEMM
+  Builder::CO l1; l1.ln = &st0; l1.ln_s = b.named_v(t + ".attn1.qkv_ln.s");
+  T qkv = b.gemm(tok, b.named_w(t + ".attn1.qkv_ln.w"), C, 3 * C, b.named_v(t + ".attn1.qkv_ln.b"), l1);
   T o1 = b.alloc(x.n, x.h, x.w, C);
-  b.attn(o1, qk.p, 2 * C, qk.p + C, 2 * C, vt.p, N * TqS, N, H, Tq, Tq, Tq, TqS, d);
-  b.release(qk);
-  b.release(vt);
-  Builder::CO r1; r1.res = &tok;
+  b.attn(o1, qkv.p, 3 * C, qkv.p + C, 3 * C, qkv.p + 2 * C, 3 * C, N, H, Tq, Tq, Tq, Tq, d);
+  b.release(qkv);
+  Builder::CO r1; r1.res = &tok; r1.stats = &st1;
   T tok1 = b.gemm(o1, b.wptr(t + ".attn1.to_out.0.weight"), C, C, b.vptr(t + ".attn1.to_out.0.bias"), r1);
   b.release(o1);
   b.release(tok);
-  // attn2 (cross, K / V^T precomputed from the context)
-  T a2 = b.ln(tok1, t + ".norm2");
-  T q2 = b.gemm(a2, b.wptr(t + ".attn2.to_q.weight"), C, C, nullptr);
-  b.release(a2);
+  // attn2 (cross, K | V precomputed from the context)
+  Builder::CO l2; l2.ln = &st1; l2.ln_s = b.named_v(t + ".attn2.q_ln.s");
+  T q2 = b.gemm(tok1, b.named_w(t + ".attn2.q_ln.w"), C, C, b.named_v(t + ".attn2.q_ln.b"), l2);
   T o2 = b.alloc(x.n, x.h, x.w, C);
-  b.attn(o2, q2.p, C, kv.k.p, C, kv.vt.p, N * TkS, N, H, Tq, c.context_len, TkS, TkS, d);
+  b.attn(o2, q2.p, C, kv.kv.p, 2 * C, kv.kv.p + C, 2 * C, N, H, Tq, c.context_len, TkS, TkS, d);
   b.release(q2);
-  Builder::CO r2; r2.res = &tok1;
+  Builder::CO r2; r2.res = &tok1; r2.stats = &st2;
   T tok2 = b.gemm(o2, b.wptr(t + ".attn2.to_out.0.weight"), C, C, b.vptr(t + ".attn2.to_out.0.bias"), r2);
   b.release(o2);
   b.release(tok1);
-  // GEGLU feed-forward
-  T a3 = b.ln(tok2, t + ".norm3");
-  // ff.net.0.proj + GEGLU in one launch (act 3: value * gelu(gate) in the GEMM epilogue, 4C columns out)
+  // GEGLU feed-forward: LN3 + ff.net.0.proj + GEGLU in one launch (act 3: value * gelu(gate) in the GEMM epilogue, 4C columns out)
   T gg = b.alloc(x.n, x.h, x.w, 4 * C);
   {
-    Builder::CO og; og.act = 3; og.out = &gg;
-    b.gemm(a3, b.wptr(t + ".ff.net.0.proj.weight"), C, 8 * C, b.vptr(t + ".ff.net.0.proj.bias"), og);
+    Builder::CO og; og.act = 3; og.out = &gg; og.ln = &st2; og.ln_s = b.named_v(t + ".ff1_ln.s");
+    b.gemm(tok2, b.named_w(t + ".ff1_ln.w"), C, 8 * C, b.named_v(t + ".ff1_ln.b"), og);
   }
-  b.release(a3);
   Builder::CO r3; r3.res = &tok2;
   T tok3 = b.gemm(gg, b.wptr(t + ".ff.net.2.weight"), 4 * C, C, b.vptr(t + ".ff.net.2.bias"), r3);
   b.release(gg);
   b.release(tok2);
+  b.release_stats();
   Builder::CO ro; ro.res = &x; ro.out = out;
   T y = b.conv(tok3, p + ".proj_out", C, 1, 1, 0, ro);
   b.release(tok3);
@@ -765,12 +820,11 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
   for (int net = 0; net < 2; ++net)
     for (const Blk* ab : attn_blocks(*plans[net])) {
       CtxKV kv;
-      kv.k = b.alloc2d(N * TkS, ab->cin);
-      kv.vt = b.alloc2d(ab->cin, N * TkS);
+      kv.kv = b.alloc2d(N * TkS, 2 * ab->cin);
       bt.kv[net][std::string(nss[net]) + ab->name] = kv;
     }
 
-  // ---- context programs: fp32 [N][77][768] -> fp16 padded; K = ctx Wk^T, V^T = Wv ctx^T per attn block
+  // ---- context programs: fp32 [N][77][768] -> fp16 padded; K | V = ctx [Wk; Wv]^T per attn block, one GEMM each
   for (int net = 0; net < 2; ++net) {
     b.prog = net == 0 ? &e->p_ctx_unet : &e->p_ctx_cn;
     {
@@ -780,14 +834,8 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
     for (const Blk* ab : attn_blocks(*plans[net])) {
       const std::string t = std::string(nss[net]) + ab->name + ".transformer_blocks.0";
       const CtxKV& kv = bt.kv[net][std::string(nss[net]) + ab->name];
-      Builder::CO o; o.out = &kv.k;
-      b.gemm(bt.ctx16, b.wptr(t + ".attn2.to_k.weight"), c.context_dim, ab->cin, nullptr, o);
-      // V^T into its persistent buffer
-      ConvGemm p;
-      p.x = b.wptr(t + ".attn2.to_v.weight"); p.w = bt.ctx16.p; p.y = kv.vt.p;
-      p.B = ab->cin; p.Cin = c.context_dim; p.M = ab->cin; p.N = N * TkS; p.K = c.context_dim;
-      p.ldx = c.context_dim; p.ldw = c.context_dim; p.ldy = N * TkS;
-      b.launch_conv(p, nullptr);
+      Builder::CO o; o.out = &kv.kv;
+      b.gemm(bt.ctx16, b.named_w(t + ".attn2.to_kv"), c.context_dim, 2 * ab->cin, nullptr, o);
     }
   }
 
@@ -1188,6 +1236,17 @@ int sdeo_finalize_weights(sdeo_handle h) {
     }
   SDEO_CHECK(nmiss == 0, "sdeo_finalize_weights: %d tensors missing (%s%s)", nmiss, missing.c_str(), nmiss > 5 ? ", ..." : "");
   if (h->stage) { (void)hipFree(h->stage); h->stage = nullptr; }
+  // LayerNorm-folded copies of the Linear layers that consume a LayerNorm (rebuilt on every finalize, from the raw tensors)
+  for (const FoldJob& f : h->folds) {
+    auto vec = [&](const std::string& n) -> const float* {
+      return n.empty() ? nullptr : reinterpret_cast<const float*>(h->wslab + h->weights[h->windex.at(n)].off);
+    };
+    if (int rc = fold_layernorm(reinterpret_cast<f16*>(h->wslab + f.w_out), reinterpret_cast<float*>(h->wslab + f.s_out),
+                                reinterpret_cast<float*>(h->wslab + f.b_out), reinterpret_cast<const f16*>(h->wslab + f.w_in),
+                                vec(f.gamma), vec(f.beta), vec(f.bias), f.rows, f.C, 0))
+      return rc;
+  }
+  SDEO_HIP(hipDeviceSynchronize());
   h->finalized = true;
   return 0;
 }

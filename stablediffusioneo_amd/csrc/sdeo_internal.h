@@ -20,6 +20,20 @@ int sdeo_debug_read_stamps(int which, unsigned long long* out, int n);
 /* y = silu(x) on n fp16 elements: launch-floor probe for tools/launch_floor.py */
 int sdeo_debug_silu(void* y, const void* x, int64_t n, void* stream);
 
+/* op-level hooks for the LayerNorm fold (tests): the networks use these paths internally (csrc/net.hip build_attn).
+ * fold: w_out = fp16(w * gamma) [rows][c], s_out[rows] = row sums of w_out, b_out[rows] = bias + w beta (bias may be NULL)
+ * gemm_stats: sdeo_gemm_f16 (fp16 out) that also writes per-row (sum, sumsq) partials of y: stats fp32 [m][stats_ld][2];
+ *   *strips_out = valid partials per row (0: the plan is split-K and cannot emit them; nothing was launched)
+ * gemm_ln: y = act(LN(x) w^T + b) given the FOLDED w / s / b and the statistics of x; eps as nn.LayerNorm
+ * row_stats: one (sum, sumsq) partial per row of x */
+int sdeo_debug_fold_layernorm(void* w_out, float* s_out, float* b_out, const void* w, const float* gamma, const float* beta,
+                              const float* bias, int rows, int c, void* stream);
+int sdeo_debug_gemm_stats_f16(void* y, int ldy, const void* x, int ldx, const void* w, int ldw, const float* bias, const void* res,
+                              int ldres, int m, int n, int k, float* stats, int stats_ld, int* strips_out, void* stream);
+int sdeo_debug_gemm_ln_f16(void* y, int ldy, const void* x, int ldx, const void* w_folded, int ldw, const float* ln_s,
+                           const float* bias_folded, const float* stats, int stats_ld, int strips, int ln_c, int m, int n, int k, int act, float eps, void* workspace, size_t workspace_bytes, void* stream);
+int sdeo_debug_row_stats_f16(float* stats, int stats_ld, const void* x, int ldx, int rows, int c, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

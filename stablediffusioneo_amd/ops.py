@@ -84,6 +84,56 @@ def gemm(x, w, bias=None, res=None, act=0, scale=1.0, out_f32=False, bias_per_ro
     return y
 
 
+def fold_layernorm(w, gamma, beta, bias=None):
+    """(w * gamma as fp16 [rows][c], row sums s fp32 [rows], bias + w beta fp32 [rows]): the load-time LayerNorm fold."""
+    lib = _lib.load()
+    _need_cuda(w, gamma, beta)
+    rows, c = w.shape
+    assert w.dtype == torch.float16 and w.is_contiguous()
+    wo = torch.empty_like(w)
+    s = torch.empty((rows,), dtype=torch.float32, device=w.device)
+    b = torch.empty((rows,), dtype=torch.float32, device=w.device)
+    check(lib.sdeo_debug_fold_layernorm(ptr(wo), ptr(s), ptr(b), ptr(w), ptr(gamma), ptr(beta), ptr(bias), _i(rows), _i(c),
+                                        cur_stream()), "fold_layernorm")
+    return wo, s, b
+
+
+def gemm_with_row_stats(x, w, bias=None, res=None):
+    """y = x w^T (+bias)(+res) in fp16 plus the per-row (sum, sumsq) partials its epilogue writes: (y, stats [m][ld][2], strips).
+    When the plan for this shape is split-K the statistics come from the row_stats kernel (strips = 1), as in the networks."""
+    lib = _lib.load()
+    _need_cuda(x, w)
+    m, k = x.shape
+    n = w.shape[0]
+    y = torch.empty((m, n), dtype=torch.float16, device=x.device)
+    ld = max(1, (n + 31) // 32)
+    stats = torch.zeros((m, ld, 2), dtype=torch.float32, device=x.device)
+    strips = C.c_int(0)
+    check(lib.sdeo_debug_gemm_stats_f16(ptr(y), _i(n), ptr(x), _i(x.stride(0)), ptr(w), _i(w.stride(0)), ptr(bias), ptr(res),
+                                        _i(res.stride(0) if res is not None else 0), _i(m), _i(n), _i(k), ptr(stats), _i(ld),
+                                        C.byref(strips), cur_stream()), "gemm_stats")
+    if strips.value == 0:
+        y = gemm(x, w, bias=bias, res=res)
+        check(lib.sdeo_debug_row_stats_f16(ptr(stats), _i(ld), ptr(y), _i(n), _i(m), _i(n), cur_stream()), "row_stats")
+        return y, stats, 1
+    return y, stats, strips.value
+
+
+def gemm_layernorm(x, stats, strips, w_folded, ln_s, bias_folded, act=0, eps=1e-5):
+    """y[m][n] = act(LN(x)[m] . w[n] + b[n]) with x [m][k] raw and the fold of (w, gamma, beta, bias)."""
+    lib = _lib.load()
+    _need_cuda(x, w_folded, stats)
+    m, k = x.shape
+    n = w_folded.shape[0]
+    y = torch.empty((m, n // 2 if act == 3 else n), dtype=torch.float16, device=x.device)
+    ws = _ws(lib.sdeo_gemm_workspace_bytes(_i(m), _i(n), _i(k)), x.device)
+    check(lib.sdeo_debug_gemm_ln_f16(ptr(y), _i(y.shape[1]), ptr(x), _i(x.stride(0)), ptr(w_folded), _i(w_folded.stride(0)),
+                                     ptr(ln_s), ptr(bias_folded), ptr(stats), _i(stats.shape[1]), _i(strips), _i(k),
+                                     _i(m), _i(n), _i(k), _i(act), _f(eps), ptr(ws), C.c_size_t(ws.numel()), cur_stream()),
+          "gemm_ln")
+    return y
+
+
 def geglu_interleave(w):
     """Row order the GEGLU-fused projection expects (same map as the load-time kernel `geglu_interleave_kernel`):
     [2H][...] with rows 0..H-1 = values, H..2H-1 = gates -> blocks of 16 alternating value / gate."""
@@ -119,19 +169,19 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return y
 
 
-def attention(q, k, vt, heads, tk=None, scale=None, causal=False):
-    """q (B,Tq,H*d), k (B,TkS,H*d), vt (H*d, B*TkS) fp16 -> (B,Tq,H*d); causal masks key j > query t (Tq == tk)."""
+def attention(q, k, v, heads, tk=None, scale=None, causal=False):
+    """q (B,Tq,H*d), k (B,TkS,H*d), v (B,TkS,H*d) fp16 -> (B,Tq,H*d); causal masks key j > query t (Tq == tk)."""
     lib = _lib.load()
-    _need_cuda(q, k, vt)
+    _need_cuda(q, k, v)
     b, tq, c = q.shape
     tks = k.shape[1]
     tk = tks if tk is None else tk
     d = c // heads
     scale = d ** -0.5 if scale is None else scale
-    assert q.is_contiguous() and k.is_contiguous() and vt.is_contiguous() and vt.shape == (c, b * tks)
+    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and v.shape == k.shape
     o = torch.empty_like(q)
     fn = lib.sdeo_attention_causal_f16 if causal else lib.sdeo_attention_f16
-    check(fn(ptr(o), _i(c), ptr(q), _i(c), ptr(k), _i(k.shape[2]), ptr(vt), _i(b * tks), _i(b), _i(heads),
+    check(fn(ptr(o), _i(c), ptr(q), _i(c), ptr(k), _i(k.shape[2]), ptr(v), _i(v.shape[2]), _i(b), _i(heads),
              _i(tq), _i(tk), _i(tks), _i(tks), _i(d), _f(scale), cur_stream()), "attention")
     return o
 

@@ -235,6 +235,9 @@ def gen_blocks():
     print("blocks:", len(out), "arrays", sum(v.nbytes for v in out.values()) / 1e6, "MB")
 
 
+ETA_SEED = 20231004
+
+
 def gen_sampler():
     """DDIMSampler.sample against an analytic apply_model (A1-A5)."""
     from cldm.ddim_hacked import DDIMSampler
@@ -280,6 +283,26 @@ def gen_sampler():
     with quiet():
         sampler.make_schedule(20, ddim_eta=0.5, verbose=False)
     out["S20.sigmas_eta0.5"] = np.asarray(sampler.ddim_sigmas, dtype=np.float64)
+    # eta > 0 trajectory: the reference draws its per-step noise from the global CPU generator (`ddim_hacked.py:227`,
+    # `noise_like` -> torch.randn); the tests replay the same draws (seed ETA_SEED, one (2,4,8,8) tensor per step)
+    sampler = Harness(Model())
+    x_T = randn((2, 4, 8, 8), 2946901)
+    torch.manual_seed(ETA_SEED)
+    with quiet():
+        x0, inter = sampler.sample(20, 2, (4, 8, 8), cond, verbose=False, eta=0.5, x_T=x_T, log_every_t=1,
+                                   unconditional_guidance_scale=9.0, unconditional_conditioning=unc)
+    out["S20_eta0.5.x0"] = x0.numpy()
+    out["S20_eta0.5.x_inter"] = torch.stack(inter["x_inter"]).numpy()
+    # DDIMSampler.decode (`ddim_hacked.py:297-317`): the last t_start = 12 of 20 DDIM steps from a given latent, and
+    # stochastic_encode (`:281-295`) with the noise passed in
+    sampler = Harness(Model())
+    with quiet():
+        sampler.make_schedule(20, ddim_eta=0.0, verbose=False)
+        x_lat = randn((2, 4, 8, 8), 77)
+        xd = sampler.decode(x_lat, cond, 12, unconditional_guidance_scale=9.0, unconditional_conditioning=unc)
+        xs = sampler.stochastic_encode(x_lat, torch.tensor([7, 7]), noise=randn((2, 4, 8, 8), 78))
+    out["S20.decode_t12"] = xd.numpy()
+    out["S20.stochastic_encode_t7"] = xs.numpy()
     np.savez_compressed(os.path.join(HERE, "sampler.npz"), **out)
     print("sampler:", len(out), "arrays")
 

@@ -301,6 +301,43 @@ def test_geglu(ops, rows, c):
     assert_close(ops.geglu(a.to(DEV)), ref, what="geglu")
 
 
+LN_CASES = [  # (rows, C, N of the consuming Linear, act, residual on the producer)
+    (200, 320, 960, 0, True), (8192, 320, 960, 0, True), (512, 1280, 1280, 0, True), (128, 1280, 3840, 0, False),
+    (130, 64, 192, 0, True), (256, 96, 128, 0, False), (300, 320, 2560, 3, True), (2048, 640, 5120, 3, True),
+]
+
+
+@pytest.mark.parametrize("case", LN_CASES)
+def test_gemm_with_folded_layernorm(ops, case):
+    """BasicTransformerBlock's x + f(LN(x)) (`attention.py:381-385`) as the networks run it: the GEMM that writes x also
+    writes x's per-row (sum, sumsq); the consuming Linear runs on the raw x with LayerNorm folded in (gamma into the weights,
+    mean / rstd in the epilogue).  Reference: fp32 F.layer_norm + F.linear on the fp16 tensor the producer stored."""
+    rows, c, n, act, with_res = case
+    x0 = h16(randn((rows, c), 700)).to(DEV)
+    w0 = h16(randn((c, c), 701) * c ** -0.5).to(DEV)
+    b0 = (randn((c,), 702) * 0.1).to(DEV)
+    r0 = h16(randn((rows, c), 703)).to(DEV) if with_res else None
+    tok, stats, strips = ops.gemm_with_row_stats(x0, w0, bias=b0, res=r0)
+    tf = tok.float()
+    got_s = stats[:, :strips].sum(1)
+    assert_close(got_s[:, 0], tf.sum(1), rtol=1e-4, atol=2e-3, what=f"row sums {case} ({strips} strips)")
+    assert_close(got_s[:, 1], (tf * tf).sum(1), rtol=1e-4, atol=2e-3, what=f"row sums of squares {case}")
+    gamma = (1.0 + 0.2 * randn((c,), 704)).to(DEV)
+    beta = (0.3 * randn((c,), 705)).to(DEV)
+    w1 = h16(randn((n, c), 706) * c ** -0.5)
+    b1 = (0.1 * randn((n,), 707)).to(DEV)
+    if act == 3:
+        w1d, b1d = ops.geglu_interleave(w1).to(DEV), ops.geglu_interleave(b1.cpu()).to(DEV)
+    else:
+        w1d, b1d = w1.to(DEV), b1
+    wf, s, bf = ops.fold_layernorm(w1d, gamma, beta, b1d)
+    y = ops.gemm_layernorm(tok, stats, strips, wf, s, bf, act=act)
+    lin = F.linear(F.layer_norm(tf, (c,), gamma, beta, 1e-5), w1.to(DEV).float(), b1)
+    ref = lin if act != 3 else lin[:, : n // 2] * F.gelu(lin[:, n // 2:])
+    # two fp16 roundings on the folded weights (W, then W * gamma) instead of one on W and one on LN(x)
+    assert_close(y, ref, rtol=4e-3, atol=4e-3, what=f"LayerNorm-folded GEMM {case}")
+
+
 def test_timestep_embedding(ops):
     g = np.load(os.path.join(GOLDEN, "blocks.npz"))
     t = torch.tensor([1, 51, 501, 951, 981], dtype=torch.long)
@@ -334,8 +371,7 @@ def test_attention(ops, case):
     sp = lambda t, T: t.float().reshape(b, T, hds, d).permute(0, 2, 1, 3)
     sim = torch.einsum("bhid,bhjd->bhij", sp(q, tq), sp(k[:, :tk], tk)) * d ** -0.5
     ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(v[:, :tk], tk)).permute(0, 2, 1, 3).reshape(b, tq, c)
-    vt = v.reshape(b * tks, c).t().contiguous()
-    o = ops.attention(q.to(DEV), k.to(DEV), vt.to(DEV), hds, tk=tk)
+    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), hds, tk=tk)
     # P is rounded to fp16 before P.V (rel 4.9e-4 per term), output stored in fp16
     assert_close(o, ref, rtol=3e-3, atol=3e-3, what=f"attention {case}")
 
@@ -355,8 +391,7 @@ def test_attention_causal(ops, case):
     sim = torch.einsum("bhid,bhjd->bhij", sp(q), sp(k[:, :t])) * d ** -0.5
     sim = sim + torch.full((t, t), float("-inf")).triu(1)
     ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(v[:, :t])).permute(0, 2, 1, 3).reshape(b, t, c)
-    vt = v.reshape(b * ts, c).t().contiguous()
-    o = ops.attention(q.to(DEV), k.to(DEV), vt.to(DEV), hds, tk=t, causal=True)
+    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), hds, tk=t, causal=True)
     assert_close(o, ref, rtol=3e-3, atol=3e-3, what=f"causal attention {case}")
 
 
@@ -371,8 +406,7 @@ def test_attention_spike(ops):
     sp = lambda x: x.float().reshape(b, t, hds, d).permute(0, 2, 1, 3)
     sim = torch.einsum("bhid,bhjd->bhij", sp(q), sp(k)) * d ** -0.5
     ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(v)).permute(0, 2, 1, 3).reshape(b, t, c)
-    vt = v.reshape(b * t, c).t().contiguous()
-    o = ops.attention(q.to(DEV), k.to(DEV), vt.to(DEV), hds)
+    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), hds)
     assert_close(o, ref, rtol=3e-3, atol=3e-3, what="attention spike")
 
 

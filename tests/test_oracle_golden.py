@@ -286,3 +286,17 @@ def test_full_sd15_pass64():
             close(c[:, ::40].contiguous(), ref, atol=ATOL * max(1.0, float(g[f"pass64.control{i}.stats"][0])))
         eps = O.unet_forward(su, S.unet_plan(ucfg), x, t, ctx, ctrl)
         close(eps, g["pass64.eps"], atol=ATOL * max(1.0, float(np.abs(g["pass64.eps"]).max())))
+
+
+def test_eta_noise_trajectory(sampler):
+    """eta = 0.5: the oracle's sampler with the reference's own noise draws (global CPU generator, seed in make_golden.py)."""
+    from tests.golden.make_golden import ETA_SEED
+
+    def apply_model(x, t, c):
+        return torch.tanh(x * c) * 0.7 + 0.1 * torch.sin(t.float() / 100.0)[:, None, None, None] * x.roll(1, -1)
+
+    gen = torch.Generator(device="cpu").manual_seed(ETA_SEED)
+    x0, inter = O.ddim_sample(apply_model, randn((2, 4, 8, 8), 2946901), 20, torch.full((2, 1, 1, 1), 0.9),
+                              torch.full((2, 1, 1, 1), -0.4), 9.0, eta=0.5, noise_fn=lambda shp: torch.randn(shp, generator=gen))
+    close(x0, sampler["S20_eta0.5.x0"], rtol=1e-4, atol=2e-5)
+    close(torch.stack(inter["x_inter"]), sampler["S20_eta0.5.x_inter"], rtol=1e-4, atol=2e-5)

@@ -83,6 +83,57 @@ def test_sampler_analytic_model_vs_reference_golden():
         np.testing.assert_allclose(torch.stack(inter["x_inter"]).cpu().numpy(), g[f"S{S_}.x_inter"], rtol=2e-4, atol=2e-5)
 
 
+def test_eta_noise_decode_and_stochastic_encode_vs_reference_golden(monkeypatch):
+    """eta > 0 (`cldm/ddim_hacked.py:227-230`: sigma_t * noise drawn every step), DDIMSampler.decode (`:297-317`) and
+    stochastic_encode (`:281-295`) against the reference sampler's own outputs on the analytic apply_model.  The reference
+    draws its noise from the global CPU generator; the same draws are replayed here by routing the sampler's torch.randn
+    through the CPU generator with the golden's seed."""
+    import os
+    from stablediffusioneo_amd.cldm.ddim_hacked import DDIMSampler
+    from tests.common import GOLDEN
+    from tests.golden.make_golden import ETA_SEED
+    g = np.load(os.path.join(GOLDEN, "sampler.npz"))
+    dev = torch.device("cuda")
+
+    class Model:
+        num_timesteps = 1000
+        parameterization = "eps"
+        device = dev
+        betas = torch.tensor(g["betas"], device=dev)
+        alphas_cumprod = torch.tensor(g["alphas_cumprod"], device=dev)
+        alphas_cumprod_prev = torch.tensor(g["alphas_cumprod_prev"], device=dev)
+
+        def apply_model(self, x, t, c):
+            k = c["c_crossattn"][0]
+            return torch.tanh(x * k) * 0.7 + 0.1 * torch.sin(t.float() / 100.0)[:, None, None, None] * x.roll(1, -1)
+
+    cond = {"c_crossattn": [torch.full((2, 1, 1, 1), 0.9, device=dev)], "c_concat": None}
+    unc = {"c_crossattn": [torch.full((2, 1, 1, 1), -0.4, device=dev)], "c_concat": None}
+    real_randn = torch.randn
+    gen = torch.Generator(device="cpu").manual_seed(ETA_SEED)
+
+    def cpu_randn(*size, device=None, generator=None, **kw):
+        shape = size[0] if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else size
+        return real_randn(tuple(shape), generator=generator if generator is not None else gen).to(device if device is not None else "cpu")
+
+    x_T = randn((2, 4, 8, 8), 2946901)
+    monkeypatch.setattr(torch, "randn", cpu_randn)
+    s = DDIMSampler(Model())
+    x0, inter = s.sample(20, 2, (4, 8, 8), cond, verbose=False, eta=0.5, x_T=x_T, log_every_t=1,
+                         unconditional_guidance_scale=9.0, unconditional_conditioning=unc)
+    monkeypatch.undo()
+    np.testing.assert_allclose(torch.stack(inter["x_inter"]).cpu().numpy(), g["S20_eta0.5.x_inter"], rtol=2e-4, atol=5e-5)
+    np.testing.assert_allclose(x0.cpu().numpy(), g["S20_eta0.5.x0"], rtol=2e-4, atol=5e-5)
+    assert np.abs(g["S20_eta0.5.x0"] - g["S20.x0"]).max() > 1e-2          # the noise term is live in the golden
+    s = DDIMSampler(Model())
+    s.make_schedule(20, ddim_eta=0.0, verbose=False)
+    x_lat = randn((2, 4, 8, 8), 77).to(dev)
+    xd = s.decode(x_lat, cond, 12, unconditional_guidance_scale=9.0, unconditional_conditioning=unc)
+    np.testing.assert_allclose(xd.cpu().numpy(), g["S20.decode_t12"], rtol=2e-4, atol=2e-5)
+    xs = s.stochastic_encode(x_lat, torch.tensor([7, 7], device=dev), noise=randn((2, 4, 8, 8), 78).to(dev))
+    np.testing.assert_allclose(xs.cpu().numpy(), g["S20.stochastic_encode_t7"], rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("guess_mode", [False, True])
 def test_ddim_sample_vs_oracle(tiny_model, guess_mode):
     from stablediffusioneo_amd.cldm.ddim_hacked import DDIMSampler

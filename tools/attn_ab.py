@@ -15,7 +15,7 @@ def child():
         g = torch.Generator(device="cuda"); g.manual_seed(1)
         q = (torch.randn(2, t, c, device="cuda", generator=g) * 0.5).half()
         k = (torch.randn(2, tks, c, device="cuda", generator=g) * 0.5).half()
-        vt = torch.randn(c, 2 * tks, device="cuda", generator=g).half()
+        vt = torch.randn(2, tks, c, device="cuda", generator=g).half()
         us = min(timeit(lambda: ops.attention(q, k, vt, 8, tk=tk), iters=10) for _ in range(3))
         out.append(f"T{t}/Tk{tk}/d{d}={us:7.1f}us")
     print(f"{os.environ.get('SDEO_LIB', 'in-tree'):>40s}: " + "  ".join(out), flush=True)

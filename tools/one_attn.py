@@ -6,7 +6,7 @@ from stablediffusioneo_amd import ops
 T, d = int(sys.argv[1]), int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 c = 8 * d
-q = torch.randn(2, T, c, device="cuda").half(); k = torch.randn(2, T, c, device="cuda").half(); vt = torch.randn(c, 2 * T, device="cuda").half()
+q = torch.randn(2, T, c, device="cuda").half(); k = torch.randn(2, T, c, device="cuda").half(); vt = torch.randn(2, T, c, device="cuda").half()
 for _ in range(reps):
     ops.attention(q, k, vt, 8)
 torch.cuda.synchronize()
