@@ -17,47 +17,11 @@ import numpy as np
 import torch
 
 from . import spec as S
+from .annotator.util import HWC3, resize_image, target_size  # noqa: F401  (`from annotator.util import resize_image, HWC3`, canny2image_torch.py:6)
 from .cldm.ddim_hacked import DDIMSampler
 from .cldm.model import create_model
 
 save_memory = False     # `config.py:1`
-
-
-def HWC3(x):
-    """`annotator/util.py:9-25`."""
-    assert x.dtype == np.uint8
-    if x.ndim == 2:
-        x = x[:, :, None]
-    H, W, C = x.shape
-    assert C in (1, 3, 4)
-    if C == 3:
-        return x
-    if C == 1:
-        return np.concatenate([x, x, x], axis=2)
-    color = x[:, :, 0:3].astype(np.float32)
-    alpha = x[:, :, 3:4].astype(np.float32) / 255.0
-    return (color * alpha + 255.0 * (1.0 - alpha)).clip(0, 255).astype(np.uint8)
-
-
-def target_size(H, W, resolution):
-    """size rule of `annotator/util.py:28-38` (shorter side -> resolution, both rounded to multiples of 64)."""
-    k = float(resolution) / min(H, W)
-    return int(np.round(H * k / 64.0)) * 64, int(np.round(W * k / 64.0)) * 64
-
-
-def resize_image(input_image, resolution):
-    H, W, _ = input_image.shape
-    Ht, Wt = target_size(H, W, resolution)
-    if (Ht, Wt) == (H, W):
-        return input_image
-    try:
-        import cv2
-        k = float(resolution) / min(H, W)
-        return cv2.resize(input_image, (Wt, Ht), interpolation=cv2.INTER_LANCZOS4 if k > 1 else cv2.INTER_AREA)
-    except ImportError:     # cv2 is not part of this image: area/bicubic resampling through torch
-        t = torch.from_numpy(input_image).permute(2, 0, 1)[None].float()
-        t = torch.nn.functional.interpolate(t, size=(Ht, Wt), mode="area" if Ht < H else "bicubic")
-        return t[0].permute(1, 2, 0).clamp(0, 255).round().to(torch.uint8).numpy()
 
 
 def synthetic_text_encoder(prompts, length=77, dim=768):

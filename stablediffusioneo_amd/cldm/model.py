@@ -37,7 +37,7 @@ def load_state_dict(ckpt_path, location="cpu"):
 _NAMED = {"sd15": (S.UNET_SD15, S.VAE_SD15), "tiny": (S.UNET_TINY, S.VAE_TINY)}
 
 
-def create_model(config_path=None, cond_stage_model=None, device=None):
+def create_model(config_path=None, cond_stage_model=None, device=None, weight_bits=16):
     ucfg, vcfg = _NAMED["sd15"]
     if isinstance(config_path, str) and config_path in _NAMED:
         ucfg, vcfg = _NAMED[config_path]
@@ -52,7 +52,7 @@ def create_model(config_path=None, cond_stage_model=None, device=None):
                                 attention_resolutions=tuple(u.get("attention_resolutions", (4, 2, 1))),
                                 channel_mult=tuple(u.get("channel_mult", (1, 2, 4, 4))), num_heads=u.get("num_heads", 8),
                                 context_dim=u.get("context_dim", 768))
-    rt = SdeoRuntime(ucfg, vcfg, device=device)
+    rt = SdeoRuntime(ucfg, vcfg, device=device, weight_bits=weight_bits)
     model = ControlLDM(rt, cond_stage_model=cond_stage_model)
     print(f"Loaded model config from [{config_path}]")
     return model

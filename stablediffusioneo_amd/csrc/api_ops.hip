@@ -51,6 +51,14 @@ int sdeo_groupnorm_nhwc_f16(void* y, const void* x, const float* gamma, const fl
                         S(stream));
 }
 
+static thread_local const void* g_next_q8 = nullptr;
+static thread_local const float* g_next_q8_scale = nullptr;
+static void take_fp8(ConvGemm& p) {           // sdeo_debug_next_weights_fp8: one-shot
+  if (!g_next_q8) return;
+  p.w = (const f16*)g_next_q8; p.wscale = g_next_q8_scale; p.ldw = p.K;
+  g_next_q8 = nullptr; g_next_q8_scale = nullptr;
+}
+
 static int fill_conv(ConvGemm& p, int n, int h, int w, int cin, int cout, int ksize, int stride, int upsample2x) {
   SDEO_CHECK(ksize == 1 || ksize == 3, "conv2d: ksize %d unsupported", ksize);
   SDEO_CHECK(stride == 1 || stride == 2, "conv2d: stride %d unsupported", stride);
@@ -78,6 +86,17 @@ int sdeo_canny_u8(const uint8_t* img_hwc, int h, int w, int c, float low_thresho
   return canny_u8(img_hwc, h, w, c, low_threshold, high_threshold, edges, control_chw, workspace, workspace_bytes, S(stream));
 }
 
+int sdeo_resize_lanczos4_u8(uint8_t* dst, const uint8_t* src, int h, int w, int c, int dst_h, int dst_w, const int32_t* x_first_tap,
+                            const int16_t* x_coeffs, const int32_t* y_first_tap, const int16_t* y_coeffs, void* stream) {
+  return resize_lanczos4_u8(dst, src, h, w, c, dst_h, dst_w, x_first_tap, x_coeffs, y_first_tap, y_coeffs, S(stream));
+}
+
+int sdeo_resize_area_u8(uint8_t* dst, const uint8_t* src, int h, int w, int c, int dst_h, int dst_w, const int32_t* x_start,
+                        const int32_t* x_index, const float* x_weight, const int32_t* y_start, const int32_t* y_index,
+                        const float* y_weight, void* stream) {
+  return resize_area_u8(dst, src, h, w, c, dst_h, dst_w, x_start, x_index, x_weight, y_start, y_index, y_weight, S(stream));
+}
+
 int sdeo_debug_read_stamps(int which, unsigned long long* out, int n) {
   return which ? conv_halo_read_stamps(out, n) : conv_gemm_read_stamps(out, n);
 }
@@ -95,6 +114,7 @@ int sdeo_conv2d_nhwc_f16(void* y, const void* x, const void* w_krsc, const float
   if (int rc = fill_conv(p, n, h, w, cin, cout, ksize, stride, upsample2x)) return rc;
   p.x = (const f16*)x; p.w = (const f16*)w_krsc; p.y = (f16*)y; p.bias = bias; p.bias2 = bias2; p.res = (const f16*)res;
   p.act = act; p.scale = scale; p.workspace = (float*)workspace; p.workspace_bytes = workspace_bytes;
+  take_fp8(p);
   return conv_gemm(p, S(stream));
 }
 
@@ -119,8 +139,14 @@ int sdeo_gemm_f16(void* y, int ldy, const void* x, int ldx, const void* w, int l
   p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldres = ldres;
   p.act = act; p.scale = scale; p.bias_per_row = bias_per_row;
   p.workspace = (float*)workspace; p.workspace_bytes = workspace_bytes;
+  take_fp8(p);
   return conv_gemm(p, S(stream));
 }
+
+int sdeo_debug_quantize_fp8_rows(void* w_f16_inout, void* q_out, float* scale_out, int rows, int cols, void* stream) {
+  return quantize_fp8_rows((uint8_t*)q_out, scale_out, (f16*)w_f16_inout, rows, cols, cols, cols, S(stream));
+}
+void sdeo_debug_next_weights_fp8(const void* q, const float* scale) { g_next_q8 = q; g_next_q8_scale = scale; }
 
 int sdeo_debug_fold_layernorm(void* w_out, float* s_out, float* b_out, const void* w, const float* gamma, const float* beta,
                               const float* bias, int rows, int c, void* stream) {

@@ -21,6 +21,8 @@
 //    zero chunks in LDS, PV pads to a multiple of 32 rows.
 //  * K / V tiles are register-staged and double-buffered: the next tile's global loads are issued before
 //    the MFMA phase and written to the other LDS buffer after it.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace sdeo {
@@ -104,7 +106,10 @@ void attention_kernel(const AP p) {
 
   // per-thread staging state, hoisted out of the key loop: source pointers (advanced by one tile per call) and LDS
   // destinations of the 16-byte chunks this thread moves
-  f16x8 kr[KPASS], vr[KPASS];
+  // DEEP: two register sets, the loads of a tile are issued TWO tiles ahead (small head dims, where a tile's compute is
+  // shorter than a global round trip); otherwise one set, loads issued at the top of the previous tile
+  constexpr bool DEEP = D16 <= 5;
+  f16x8 kr[DEEP ? 2 : 1][KPASS], vr[DEEP ? 2 : 1][KPASS];
   const f16* kptr[KPASS];
   const f16* vptr[KPASS];
   int krow[KPASS], kdst[KPASS], vdst[KPASS];
@@ -120,26 +125,30 @@ void attention_kernel(const AP p) {
     vdst[i] = use ? row * VROW + c * 16 : -1;        // chunk slots past d keep their zeros / the ones column
   }
   const size_t kstep = (size_t)64 * p.ldk, vstep = (size_t)64 * p.ldv;
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](auto SET, int kt) {
+    constexpr int rs = SET.value;
     const int key0 = kt * 64;
 #pragma unroll
     for (int i = 0; i < KPASS; ++i) {
       const bool ok = key0 + krow[i] < p.Tk;        // rows >= Tk: K zero (masked anyway), V zero (P is 0 there, V must be finite)
-      kr[i] = ok ? *reinterpret_cast<const f16x8*>(kptr[i]) : zero8;
-      vr[i] = ok ? *reinterpret_cast<const f16x8*>(vptr[i]) : zero8;
+      kr[rs][i] = ok ? *reinterpret_cast<const f16x8*>(kptr[i]) : zero8;
+      vr[rs][i] = ok ? *reinterpret_cast<const f16x8*>(vptr[i]) : zero8;
       kptr[i] += kstep;
       vptr[i] += vstep;
     }
   };
-  auto store_tile = [&](int stage) {
+  auto store_tile = [&](auto SET, int stage) {
+    constexpr int rs = SET.value;
     char* ks_ = smem + stage * STAGE;
     char* vs_ = ks_ + KBYTES;
 #pragma unroll
     for (int i = 0; i < KPASS; ++i) {
-      if (kdst[i] >= 0) *reinterpret_cast<f16x8*>(ks_ + kdst[i]) = kr[i];
-      if (vdst[i] >= 0) *reinterpret_cast<f16x8*>(vs_ + vdst[i]) = vr[i];
+      if (kdst[i] >= 0) *reinterpret_cast<f16x8*>(ks_ + kdst[i]) = kr[rs][i];
+      if (vdst[i] >= 0) *reinterpret_cast<f16x8*>(vs_ + vdst[i]) = vr[rs][i];
     }
   };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
   // the V tiles start as zeros (+ the ones column): staging only ever writes the chunk slots below d
   for (int st = 0; st < 2; ++st)
     for (int off = tid * 16; off < VBYTES; off += NT * 16) *reinterpret_cast<f16x8*>(smem + st * STAGE + KBYTES + off) = zero8;
@@ -153,14 +162,18 @@ void attention_kernel(const AP p) {
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  load_tile(0);
-  store_tile(0);
+  load_tile(S0{}, 0);
+  store_tile(S0{}, 0);
+  if constexpr (DEEP) {
+    if (ntiles > 1) load_tile(S1{}, 1);             // set 1 carries the odd tiles, set 0 the even ones
+    if (ntiles > 2) load_tile(S0{}, 2);
+  }
   __syncthreads();
 
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < ntiles;
-    if (more) load_tile(kt + 1);
+  // one 64-key tile; at its end the NEXT tile (loaded two iterations ago) goes from registers to the other LDS buffer and the
+  // freed register set takes the loads of the tile after that: a global round trip has two tiles of compute to hide behind
+  // the compute of one 64-key tile (QK^T, online softmax, P V) out of LDS buffer `cur`
+  auto compute = [&](int kt, int cur) __attribute__((always_inline)) {
     const char* ks_ = smem + cur * STAGE;
     const char* vs_ = ks_ + KBYTES;
 
@@ -238,8 +251,31 @@ void attention_kernel(const AP p) {
           o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
         }
       }
-    if (more) store_tile(cur ^ 1);
-    __syncthreads();
+  };
+  if constexpr (DEEP) {
+    // at the end of a tile the NEXT tile (loaded two iterations ago) goes from registers to the other LDS buffer and the freed
+    // register set takes the loads of the tile after that: a global round trip has two tiles of compute to hide behind
+    for (int kt = 0; kt < ntiles; kt += 2) {
+      compute(kt, 0);
+      if (kt + 1 < ntiles) store_tile(S1{}, 1);
+      if (kt + 3 < ntiles) load_tile(S1{}, kt + 3);
+      __syncthreads();
+      if (kt + 1 < ntiles) {
+        compute(kt + 1, 1);
+        if (kt + 2 < ntiles) store_tile(S0{}, 0);
+        if (kt + 4 < ntiles) load_tile(S0{}, kt + 4);
+        __syncthreads();
+      }
+    }
+  } else {
+    for (int kt = 0; kt < ntiles; ++kt) {
+      const int cur = kt & 1;
+      const bool more = kt + 1 < ntiles;
+      if (more) load_tile(S0{}, kt + 1);
+      compute(kt, cur);
+      if (more) store_tile(S0{}, cur ^ 1);
+      __syncthreads();
+    }
   }
 
   if constexpr (KS == 2) {

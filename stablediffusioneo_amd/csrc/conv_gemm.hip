@@ -27,6 +27,7 @@
 #include <array>
 #include <map>
 
+#include <type_traits>
 #include <utility>
 
 #include "conv_inl.h"
@@ -42,12 +43,17 @@ namespace sdeo {
 // both roles: the loaders retire step `it` (counted vmcnt) BEFORE barrier `it`, the MFMA waves read it AFTER; the
 // loaders refill slot (it-1) % STAGES after barrier `it`, which every MFMA wave only reaches once its reads of step
 // it-1 have fed its MFMAs.
-template <int BM, int BN, int STAGES, bool UPS, bool WS>
+// W8: the weights are fp8 (OCP e4m3fn, one byte per element, per-output-channel power-of-two scale applied in the epilogue):
+// a weight-tile row is 64 bytes per K-step instead of 128, one DMA pass of the 256 loading threads covers 64 rows, and the
+// MFMA waves widen each 8-byte fragment to fp16 in registers (v_cvt_scalef32_pk_f16_fp8, exact) right before its MFMAs.
+// The activations, the accumulation and the epilogue are those of the fp16 kernel; what changes is the bytes streamed.
+template <int BM, int BN, int STAGES, bool UPS, bool WS, bool W8 = false>
 __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP p) {
   constexpr int BK = 64, RPP = 32;
-  constexpr int XP = BM / RPP, WP = BN / RPP, L = XP + WP;     // DMA instructions per loading thread per stage
+  constexpr int WRPP = W8 ? 64 : 32;                           // weight rows per DMA pass
+  constexpr int XP = BM / RPP, WP = (BN + WRPP - 1) / WRPP, L = XP + WP;     // DMA instructions per loading thread per stage
   constexpr int TM = BM / 2, TN = BN / 2, MI = TM / 16, NI = TN / 16;
-  constexpr int XBYTES = BM * BK * 2, WBYTES = BN * BK * 2, STAGE = XBYTES + WBYTES;
+  constexpr int XBYTES = BM * BK * 2, WBYTES = WP * 4096, STAGE = XBYTES + WBYTES;
   constexpr int PF = STAGES - 1;                                // K-steps of loads issued ahead of the compute
   static_assert(PF >= 1 && PF <= 7, "ring depth");
 
@@ -120,10 +126,22 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
     }
 #pragma unroll
     for (int i = 0; i < WP; ++i) {
-      const int n = n0 + lrow + i * RPP;
-      const bool nv = n < p.N && !dbg_on(p, 2);
-      wptr[i] = nv ? reinterpret_cast<const char*>(p.w + (size_t)n * p.ldw + (size_t)kbeg * BK + cl * 8) : zero;
-      winc[i] = nv ? BK * 2 : 0;
+      if constexpr (!W8) {
+        const int n = n0 + lrow + i * RPP;
+        const bool nv = n < p.N && !dbg_on(p, 2);
+        wptr[i] = nv ? reinterpret_cast<const char*>(p.w + (size_t)n * p.ldw + (size_t)kbeg * BK + cl * 8) : zero;
+        winc[i] = nv ? BK * 2 : 0;
+      } else {
+        // 64-byte rows: thread (row = tid >> 2, 16-byte chunk c = tid & 3) of each pass; the LDS image rotates the four chunks
+        // of row r by (r >> 2) & 3 (source-side, the DMA destination is lane-linear) so that the 8-byte fragment reads of a
+        // 32-lane half (16 rows x 2 k-groups) cover all 64 banks once
+        const int r8 = (tid >> 2) + i * 64, c = tid & 3;
+        const int n = n0 + r8;
+        const bool nv = r8 < BN && n < p.N && !dbg_on(p, 2);
+        const int csrc = (c - ((r8 >> 2) & 3)) & 3;
+        wptr[i] = nv ? reinterpret_cast<const char*>(p.w) + (size_t)n * p.ldw + (size_t)kbeg * BK + csrc * 16 : zero;
+        winc[i] = nv ? BK : 0;
+      }
     }
   }
 
@@ -229,12 +247,28 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int swl = (frow >> 1) & 7;                      // == (row >> 1) & 7: every fragment row is frow + multiple of 16
   const unsigned xa0 = lds0 + (wm * TM + frow) * 128 + ((fq ^ swl) << 4), xa1 = lds0 + (wm * TM + frow) * 128 + (((4 + fq) ^ swl) << 4);
-  const unsigned wa0 = xa0 + XBYTES + (wn * TN - wm * TM) * 128, wa1 = xa1 + XBYTES + (wn * TN - wm * TM) * 128;
-  auto read_half = [&](const char* xs, const char* wsm, int kk, f16x8 (&wf)[NI], f16x8 (&xf)[MI]) {
+  // weight fragment addresses: fp16 rows of 128 bytes (chunk swizzle as for the activations) or fp8 rows of 64 bytes, 8-byte
+  // k-group g = kk * 4 + fq stored at group (g + 2 ((row >> 2) & 3)) & 7
+  const int g8 = (fq + 2 * ((frow >> 2) & 3)) & 7;
+  const unsigned wa0 = W8 ? lds0 + XBYTES + (wn * TN + frow) * 64 + g8 * 8 : xa0 + XBYTES + (wn * TN - wm * TM) * 128;
+  const unsigned wa1 = W8 ? lds0 + XBYTES + (wn * TN + frow) * 64 + (g8 ^ 4) * 8 : xa1 + XBYTES + (wn * TN - wm * TM) * 128;
+  constexpr int WSTEP = W8 ? 1024 : 2048;               // bytes between fragment rows i and i + 1 (16 tile rows)
+  typedef std::conditional_t<W8, uint2, f16x8> wfrag;   // a weight fragment as it sits in LDS
+  auto widen = [](const wfrag& w) -> f16x8 {
+    if constexpr (W8) {
+      const f16x2 a = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.x, 1.0f, false), b = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.x, 1.0f, true);
+      const f16x2 c = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.y, 1.0f, false), d = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w.y, 1.0f, true);
+      return f16x8{a[0], a[1], b[0], b[1], c[0], c[1], d[0], d[1]};
+    } else {
+      return w;
+    }
+  };
+  auto read_half = [&](const char* xs, const char* wsm, int kk, wfrag (&wf)[NI], f16x8 (&xf)[MI]) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int row = wn * TN + i * 16 + frow;
-      wf[i] = *reinterpret_cast<const f16x8*>(wsm + row * 128 + swz_chunk<64>(row, kk * 4 + fq) * 16);
+      if constexpr (W8) wf[i] = *reinterpret_cast<const uint2*>(wsm + row * 64 + ((kk * 4 + fq + 2 * ((row >> 2) & 3)) & 7) * 8);
+      else wf[i] = *reinterpret_cast<const f16x8*>(wsm + row * 128 + swz_chunk<64>(row, kk * 4 + fq) * 16);
     }
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
@@ -242,20 +276,23 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
       xf[j] = *reinterpret_cast<const f16x8*>(xs + row * 128 + swz_chunk<64>(row, kk * 4 + fq) * 16);
     }
   };
-  auto mma_half = [&](const f16x8 (&wf)[NI], const f16x8 (&xf)[MI]) {
+  auto mma_half = [&](const wfrag (&wf)[NI], const f16x8 (&xf)[MI]) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NI; ++i) {
+      const f16x8 w = widen(wf[i]);
 #pragma unroll
       for (int j = 0; j < MI; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, xf[j], acc[i][j], 0, 0, 0);
+    }
   };
   auto compute = [&](int it) {
     if constexpr (DB) {
       const unsigned sb = (it % STAGES) * STAGE;
-      f16x8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
-      static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wf0[I.value], wa0 + sb); });
+      wfrag wf0[NI], wf1[NI];
+      f16x8 xf0[MI], xf1[MI];
+      static_for<NI>([&](auto I) { lds_read_w<I.value * WSTEP>(wf0[I.value], wa0 + sb); });
       static_for<MI>([&](auto J) { lds_read128<J.value * 2048>(xf0[J.value], xa0 + sb); });
-      static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wf1[I.value], wa1 + sb); });
+      static_for<NI>([&](auto I) { lds_read_w<I.value * WSTEP>(wf1[I.value], wa1 + sb); });
       static_for<MI>([&](auto J) { lds_read128<J.value * 2048>(xf1[J.value], xa1 + sb); });
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NI + MI) : "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -270,7 +307,8 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
       const char* wsm = xs + XBYTES;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        f16x8 wf[NI], xf[MI];
+        wfrag wf[NI];
+        f16x8 xf[MI];
         read_half(xs, wsm, kk, wf, xf);
         __builtin_amdgcn_sched_barrier(0);
         mma_half(wf, xf);
@@ -290,15 +328,16 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
         // halves of MFMAs.  A wave reaches barrier it+1 only after lgkmcnt(0), i.e. with all its reads of step `it` in
         // registers, which is what allows the loaders to refill that slot.  Register sets are rewritten only after the
         // MFMAs reading them have issued (an LDS return is >60 clocks away, an MFMA reads its operands at issue).
-        f16x8 wf0[NI], xf0[MI], wf1[NI], xf1[MI];
+        wfrag wf0[NI], wf1[NI];
+        f16x8 xf0[MI], xf1[MI];
         auto reads0 = [&](unsigned sb) {
           if (dbg_on(p, 16)) return;
-          static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wf0[I.value], wa0 + sb); });
+          static_for<NI>([&](auto I) { lds_read_w<I.value * WSTEP>(wf0[I.value], wa0 + sb); });
           static_for<MI>([&](auto J) { lds_read128<J.value * 2048>(xf0[J.value], xa0 + sb); });
         };
         auto reads1 = [&](unsigned sb) {
           if (dbg_on(p, 16)) return;
-          static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wf1[I.value], wa1 + sb); });
+          static_for<NI>([&](auto I) { lds_read_w<I.value * WSTEP>(wf1[I.value], wa1 + sb); });
           static_for<MI>([&](auto J) { lds_read128<J.value * 2048>(xf1[J.value], xa1 + sb); });
         };
         stamp(p, 1);
@@ -542,6 +581,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KP p) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) v += t[u];
   }
+  if (p.wscale) v *= *reinterpret_cast<const f32x4*>(p.wscale + n);       // fp8 weights: per-output-channel scale
   if (p.ln_stats) {                 // LayerNorm folded into the GEMM: see KP::ln_stats
     float r, rm;
     ln_row_scalars(p, m, r, rm);
@@ -637,7 +677,12 @@ void conv_gemm_debug_force(int tile, int splitk) { g_force_tile = tile; g_force_
 typedef std::array<int, 10> ShapeKey;
 static std::map<ShapeKey, std::pair<int, int>> g_tuned;
 // (the `ups` slot doubles as the epilogue class: 2 = GEGLU pair epilogue, whose tile menu is restricted)
-static ShapeKey key_of(const ConvGemm& p) { return {p.M, p.N, p.K, p.Cin, p.R, p.stride, p.act == 3 ? 2 : p.ups, p.Hi, p.Wi, p.B}; }
+// (... and + 4 marks fp8 weights: a different kernel family with its own measurements)
+static ShapeKey key_of(const ConvGemm& p) {
+  return {p.M, p.N, p.K, p.Cin, p.R, p.stride, (p.act == 3 ? 2 : p.ups) + (p.wscale ? 4 : 0), p.Hi, p.Wi, p.B};
+}
+// tiles instantiated with fp8 weights (the weight-bound shapes: few rows, long K)
+static bool tile_has_w8(int t) { return t == 1 || t == 2 || t == 6 || t == 9 || t == 19 || t == 20; }
 
 static Plan make_plan(const ConvGemm& p) {
   Plan best{};
@@ -649,7 +694,7 @@ static Plan make_plan(const ConvGemm& p) {
     auto it = g_tuned.find(key_of(p));
     if (it != g_tuned.end() && !(pair && ((kTiles[it->second.first].bn / 2) % 32 != 0 || it->second.second != 1))) {
       const TileCfg& c = kTiles[it->second.first];
-      if (c.kind != TK_HALO || halo_ok(p, c))
+      if ((c.kind != TK_HALO || halo_ok(p, c)) && (!p.wscale || tile_has_w8(it->second.first)))
         return Plan{it->second.first, it->second.second, plan_nk(p, c), plan_tiles_m(p, c), cdiv(p.N, c.bn)};
     }
   }
@@ -658,6 +703,7 @@ static Plan make_plan(const ConvGemm& p) {
     const TileCfg& c = kTiles[t];
     auto usable = [&](int ti) {
       const TileCfg& cc = kTiles[ti];
+      if (p.wscale && !tile_has_w8(ti)) return false;
       if (cc.kind == TK_HALO) return halo_ok(p, cc);
       return (cc.kind == TK_DMA) == fast && !(pair && (cc.bn / 2) % 32 != 0);
     };
@@ -706,6 +752,8 @@ int conv_gemm_stats_strips(const ConvGemm& p) {
   return pl.splitk == 1 ? cdiv(p.N, plan_tn(pl)) : 0;
 }
 
+bool conv_gemm_plan_is_halo(const ConvGemm& p) { return kTiles[make_plan(p).tile].kind == TK_HALO; }
+
 size_t conv_gemm_workspace_bytes(const ConvGemm& p) {
   const Plan pl = make_plan(p);
   return pl.splitk > 1 ? (size_t)pl.splitk * p.M * p.N * sizeof(float) : 0;
@@ -729,6 +777,14 @@ static int g_ws = -1;     // wave-specialised variant: -1 = SDEO_GEMM_WS env (de
 static bool use_ws() {
   if (g_ws < 0) { const char* e = getenv("SDEO_GEMM_WS"); g_ws = e ? atoi(e) : 1; }
   return g_ws != 0;
+}
+
+// fp8-weight instantiations: wave-specialised only, no folded Upsample (the weight-bound convs have neither)
+template <int BM, int BN, int ST>
+static int launch_dma_w8(const KP& kp, int tiles, hipStream_t stream) {
+  static bool done = false;
+  constexpr int smem = ST * (BM * 128 + (BN + 63) / 64 * 4096) + BM * 8;
+  return launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, true, true>, smem, &done, kp, tiles, stream, 512);
 }
 
 template <int BM, int BN, int ST>
@@ -765,7 +821,11 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
   if (p.act == 3)
     SDEO_CHECK(p.N % 32 == 0 && p.y && !p.y32 && !p.res && !p.bias2 && !p.bias_per_row && p.ldy >= p.N / 2 && p.scale == 1.0f,
                "conv_gemm: GEGLU epilogue needs N %% 32 == 0 (N=%d), fp16 output with ldy >= N/2 and no residual / bias2", p.N);
+  if (p.wscale)
+    SDEO_CHECK(p.Cin % 64 == 0 && !p.ups && p.ldw % 16 == 0 && !p.bias_per_row,
+               "conv_gemm: fp8 weights need Cin %% 64 == 0 (Cin=%d), no folded upsample and 16-byte aligned rows (ldw=%d bytes)", p.Cin, p.ldw);
   const Plan pl = make_plan(p);
+  SDEO_CHECK(!p.wscale || (tile_has_w8(pl.tile) && kTiles[pl.tile].kind == TK_DMA), "conv_gemm: no fp8-weight plan for this shape");
   SDEO_CHECK(p.act != 3 || (pl.splitk == 1 && (kTiles[pl.tile].bn / 2) % 32 == 0), "conv_gemm: no GEGLU-capable plan");
   KP kp{};
   kp.x = p.x; kp.w = p.w; kp.y = p.y; kp.y32 = p.y32; kp.bias = p.bias; kp.bias2 = p.bias2; kp.res = p.res;
@@ -775,6 +835,7 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
   kp.ups = p.ups; kp.HoWo = p.Ho * p.Wo;
   kp.ldx = p.ldx; kp.ldw = p.ldw; kp.ldy = p.ldy; kp.ldres = p.ldres; kp.ld_bias2 = p.ld_bias2;
   kp.act = p.act; kp.bias_per_row = p.bias_per_row; kp.scale = p.scale;
+  kp.wscale = p.wscale;
   if (p.ln_stats) {
     SDEO_CHECK(p.ln_s && p.ln_strips >= 1 && p.ln_ld >= p.ln_strips && p.ln_c > 0, "conv_gemm: incomplete LayerNorm-fold arguments");
     SDEO_CHECK(!p.bias_per_row && !p.y32, "conv_gemm: the LayerNorm fold applies to row-major fp16 products only");
@@ -812,6 +873,17 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
   }
   const int tiles = pl.tiles_m * pl.tiles_n;
   int rc = 0;
+  if (p.wscale) {
+    switch (pl.tile) {
+      case 1: rc = launch_dma_w8<128, 64, 3>(kp, tiles, stream); break;
+      case 2: rc = launch_dma_w8<64, 64, 4>(kp, tiles, stream); break;
+      case 6: rc = launch_dma_w8<64, 160, 3>(kp, tiles, stream); break;
+      case 9: rc = launch_dma_w8<32, 160, 4>(kp, tiles, stream); break;
+      case 19: rc = launch_dma_w8<64, 64, 8>(kp, tiles, stream); break;
+      case 20: rc = launch_dma_w8<32, 160, 6>(kp, tiles, stream); break;
+      default: return fail("conv_gemm: tile %d has no fp8-weight instantiation", pl.tile);
+    }
+  } else
   switch (pl.tile) {
     case 0: rc = launch_dma<128, 128, 3>(p.ups, kp, tiles, stream); break;
     case 1: rc = launch_dma<128, 64, 3>(p.ups, kp, tiles, stream); break;
@@ -901,6 +973,7 @@ int conv_gemm_autotune(const ConvGemm& p, hipStream_t stream) {
   for (int t : tiles) {
     const bool halo = kTiles[t].kind == TK_HALO;
     if (halo && !halo_ok(p, kTiles[t])) continue;
+    if (p.wscale && !tile_has_w8(t)) continue;
     const int nk = plan_nk(p, kTiles[t]);
     const int wgs1 = plan_tiles_m(p, kTiles[t]) * cdiv(p.N, kTiles[t].bn);
     if (p.act == 3 && (kTiles[t].bn / 2) % 32 != 0) continue;

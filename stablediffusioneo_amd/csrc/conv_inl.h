@@ -38,6 +38,9 @@ struct KP {
   const float* ln_s;       // [N]
   int ln_strips, ln_ld;
   float ln_invc, ln_eps;
+  // ---- fp8 weights (conv_gemm_dma_kernel<..., W8>): `w` points at bytes, ldw counts bytes, the accumulators are multiplied by the
+  //      per-output-channel scale before anything else in the epilogue (or in the split-K reduce)
+  const float* wscale;     // [N]; null = fp16 weights
   // ---- producer side: per-row partial (sum, sumsq) of the values this launch stores, one partial per TN-wide strip
   float* stats_out;        // [M][stats_ld][2]; null = off
   int stats_ld;
@@ -163,6 +166,15 @@ template <int NI, int MI, int TN>
 __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI], const int (&mrow)[MI], int nb, int fq, int z,
                                               const f32x4 (&bpre)[NI], bool use_bpre, char* scratch = nullptr,
                                               const float2* lnrow = nullptr) {
+  if (p.wscale && p.splitk == 1) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int n = nb + i * 16 + fq * 4;
+      const f32x4 sc = n < p.N ? *reinterpret_cast<const f32x4*>(p.wscale + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < MI; ++j) acc[i][j] *= sc;
+    }
+  }
   if (p.ln_stats && p.splitk == 1) ln_correct<NI, MI>(p, acc, mrow, nb, fq, lnrow);
   if (scratch && p.coalesce) {
     constexpr int ROWB = TN * 4 + 16;            // odd multiple of 16 bytes: the 16 rows of a block start in different banks
@@ -361,6 +373,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int OFF>
 __device__ __forceinline__ void lds_read128(f16x8& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+
+// a weight fragment as it sits in LDS: 16 bytes of fp16 or 8 bytes of fp8
+template <int OFF>
+__device__ __forceinline__ void lds_read_w(f16x8& dst, unsigned addr) { lds_read128<OFF>(dst, addr); }
+template <int OFF>
+__device__ __forceinline__ void lds_read_w(uint2& dst, unsigned addr) {
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
 
 template <int N>

@@ -412,4 +412,97 @@ int row_stats(float* stats, int ld, const f16* x, int ldx, int rows, int C, hipS
   return 0;
 }
 
+// ---- fp8 weight pack (BASELINE configs[4]; the reference's precision switch is the TensorRT builder flag,
+//      `onnx2trt_static_plugin.py:40-42`).  One wave per output row: scale = the smallest power of two with absmax / scale <= 448,
+//      codes = OCP e4m3fn (round to nearest even, gfx950's native fp8; NOT MI300's fnuz), and the fp16 matrix is overwritten with
+//      the dequantised values code * scale (exact in fp16), so kernels without an fp8 path compute with the same weights.
+__device__ __forceinline__ unsigned e4m3fn_encode(float f) {           // |f| <= 448
+  const unsigned sign = (__float_as_uint(f) >> 24) & 0x80u;
+  const float a = fabsf(f);
+  unsigned code;
+  if (a < 0.015625f) {                                                  // below 2^-6: subnormal grid of 2^-9 (8 rounds up to the
+    code = (unsigned)rintf(a * 512.0f);                                 // smallest normal, whose code is 8)
+  } else {
+    unsigned b = __float_as_uint(a);
+    b += 0x7FFFFu + ((b >> 20) & 1u);                                   // round the 23-bit mantissa to 3 bits, ties to even
+    code = (b >> 20) - ((127u - 7u) << 3);
+    if (code > 0x7Eu) code = 0x7Eu;                                     // 448 = S.1111.110
+  }
+  return sign | code;
+}
+__device__ __forceinline__ float e4m3fn_decode(unsigned c) {
+  const unsigned e = (c >> 3) & 15u, m = c & 7u;
+  const float v = e == 0 ? (float)m * 0.001953125f : __uint_as_float(((e + 120u) << 23) | (m << 20));
+  return (c & 0x80u) ? -v : v;
+}
+
+__global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(uint8_t* __restrict__ q, float* __restrict__ scale, f16* w,
+                                                                int rows, int cols, int ldw, int ldq) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  f16* wr = w + (size_t)r * ldw;
+  float amax = 0.f;
+  for (int k = lane * 8; k < cols; k += 64 * 8) {
+    const f16x8 v = *reinterpret_cast<const f16x8*>(wr + k);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf((float)v[j]));
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+  float sc = 1.0f;
+  if (amax > 0.f) {
+    int x;
+    const float m = frexpf(amax, &x);                                  // amax = m * 2^x, m in [0.5, 1);  448 = 0.875 * 2^9
+    const int e = m <= 0.875f ? x - 9 : x - 8;
+    sc = ldexpf(1.0f, e < -15 ? -15 : e);       // >= 2^-15: the smallest code (2^-9) times the scale stays on the fp16 grid (2^-24)
+  }
+  const float inv = 1.0f / sc;                                          // exact: a power of two
+  for (int k = lane * 8; k < cols; k += 64 * 8) {
+    const f16x8 v = *reinterpret_cast<const f16x8*>(wr + k);
+    f16x8 o;
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      unsigned c = e4m3fn_encode((float)v[j] * inv);
+      if (fabsf(e4m3fn_decode(c) * sc) > 65504.0f) c -= 1;            // |w| in fp16's top binade may round past fp16's maximum: next code down
+      if (j < 4) lo |= c << (8 * j); else hi |= c << (8 * (j - 4));
+      o[j] = (f16)(e4m3fn_decode(c) * sc);
+    }
+    *reinterpret_cast<uint2*>(q + (size_t)r * ldq + k) = make_uint2(lo, hi);
+    *reinterpret_cast<f16x8*>(wr + k) = o;
+  }
+  if (lane == 0) scale[r] = sc;
+}
+
+int quantize_fp8_rows(uint8_t* q, float* scale, f16* w, int rows, int cols, int ldw, int ldq, hipStream_t stream) {
+  SDEO_CHECK(q && scale && w && rows > 0 && cols > 0 && cols % 8 == 0 && ldw % 8 == 0 && ldq % 8 == 0, "quantize_fp8_rows: bad operand");
+  hipLaunchKernelGGL(quantize_fp8_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, q, scale, w, rows, cols, ldw, ldq);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+// s[r] = sum_k w[r][k]  (row sums of a LayerNorm-folded matrix after it was re-quantised: KP::ln_s must match the streamed weights)
+__global__ __launch_bounds__(256) void row_sums_kernel(float* __restrict__ s_out, const f16* __restrict__ w, int rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float ss = 0.f;
+  for (int k = lane * 8; k < C; k += 64 * 8) {
+    const f16x8 v = *reinterpret_cast<const f16x8*>(w + (size_t)r * C + k);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += (float)v[j];
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+  if (lane == 0) s_out[r] = ss;
+}
+
+int row_sums_f16(float* s_out, const f16* w, int rows, int C, hipStream_t stream) {
+  SDEO_CHECK(s_out && w && rows > 0 && C > 0 && C % 8 == 0, "row_sums_f16: bad operand");
+  hipLaunchKernelGGL(row_sums_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, s_out, w, rows, C);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace sdeo

@@ -40,11 +40,16 @@ struct ConvGemm {
   int ln_strips = 0, ln_ld = 0;
   int ln_c = 0;                // channels normalised over (= K for rows mode)
   float ln_eps = 1e-5f;
+  // fp8 weights (OCP e4m3fn): `w` points at [N][K] BYTES (ldw in bytes), wscale[N] = per-output-channel scale (a power of two:
+  // the product is then bit-identical to the fp16 kernel run on the dequantised weights).  Implicit-GEMM DMA kernel only.
+  const float* wscale = nullptr;
   // emit per-row partial (sum, sumsq) of the stored fp16 values: stats_out[m][stats_ld][2], conv_gemm_stats_strips(p) valid
   float* stats_out = nullptr;
   int stats_ld = 0;
 };
 int conv_gemm(const ConvGemm& p, hipStream_t stream);
+// whether the plan chosen for p is a halo-reuse 3x3 kernel (which has no fp8-weight variant)
+bool conv_gemm_plan_is_halo(const ConvGemm& p);
 // strips (partials per row) a launch of p writes to stats_out; 0 when the chosen plan cannot emit them (split-K)
 int conv_gemm_stats_strips(const ConvGemm& p);
 // measurement only: phase stamps of the last launch of an implicit-GEMM / halo kernel (SDEO_DBG_GEMM bit 6), see conv_inl.h
@@ -117,6 +122,9 @@ int fold_layernorm(f16* w_out, float* s_out, float* b_out, const f16* w, const f
                    const float* bias, int rows, int C, hipStream_t stream);
 // stats[r][ld][2] <- one (sum, sumsq) partial per row of x [rows][C]
 int row_stats(float* stats, int ld, const f16* x, int ldx, int rows, int C, hipStream_t stream);
+// fp8 weight pack: q[r][0:cols] = e4m3fn codes of w[r] / scale[r] (scale = power of two, absmax / scale <= 448) and w <- code * scale
+int quantize_fp8_rows(uint8_t* q, float* scale, f16* w, int rows, int cols, int ldw, int ldq, hipStream_t stream);
+int row_sums_f16(float* s_out, const f16* w, int rows, int C, hipStream_t stream);
 // CLIP text embeddings: out[(b*T + t)][0:W] = tok_emb[ids[b*T + t]][0:W] + pos_emb[t][0:W]   (ids are clamped to [0, vocab))
 int embed_tokens(f16* out, const int32_t* ids, const f16* tok_emb, const f16* pos_emb, int B, int T, int W, int vocab,
                  hipStream_t stream);
@@ -125,6 +133,11 @@ int embed_tokens(f16* out, const int32_t* ids, const f16* tok_emb, const f16* po
 size_t canny_workspace_bytes(int H, int W);
 int canny_u8(const uint8_t* img, int H, int W, int C, float low_threshold, float high_threshold, uint8_t* edges, float* control,
              void* workspace, size_t workspace_bytes, hipStream_t stream);
+// cv2.resize on 8-bit HWC images (csrc/resize.hip); the coefficient tables are built on the host (annotator/util.py)
+int resize_lanczos4_u8(uint8_t* dst, const uint8_t* src, int h, int w, int c, int dh, int dw, const int* x0, const short* ax,
+                       const int* y0, const short* by, hipStream_t stream);
+int resize_area_u8(uint8_t* dst, const uint8_t* src, int h, int w, int c, int dh, int dw, const int* xstart, const int* xidx,
+                   const float* xw, const int* ystart, const int* yidx, const float* yw, hipStream_t stream);
 // classifier-free guidance + DDIM update on NCHW fp32 latents (ddim_hacked.py:192,208-231)
 int cfg_ddim_step(float* x_prev, float* pred_x0, const float* x, const float* eps_c, const float* eps_u, const float* noise,
                   float cfg_scale, float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at, int64_t n,

@@ -200,6 +200,9 @@ struct ProfRec { std::string key; double flops, bytes; hipEvent_t a, b; };
 
 // LayerNorm folded into a Linear at weight-finalisation time (fold_layernorm): offsets into the weight slab
 struct FoldJob { size_t w_out, s_out, b_out, w_in; std::string gamma, beta, bias; int rows, C; };
+// a [rows][cols] fp16 matrix of the UNet / ControlNet that a conv / GEMM streams as its weight operand: with fp8 weights
+// (sdeo_set_weight_precision) it gets an e4m3fn copy + per-row scales and its fp16 copy is replaced by the dequantised values
+struct QRegion { size_t off; int rows, cols; size_t q_off, s_off; };
 
 }  // namespace
 
@@ -212,6 +215,11 @@ struct sdeo_handle_s {
   std::unordered_map<std::string, int> windex;
   std::unordered_map<std::string, size_t> named_off;   // extra named regions (stacked parents, LayerNorm-folded copies)
   std::vector<FoldJob> folds;
+  std::vector<QRegion> qregions;
+  std::unordered_map<size_t, int> qindex;              // fp16 slab offset -> qregions index
+  int weight_bits = 16;                                // 8: fp8 e4m3fn weights for the UNet / ControlNet matrices
+  char* q8slab = nullptr;                              // fp8 codes + scales (allocated at the first fp8 finalize)
+  size_t q8_bytes = 0;
   char* wslab = nullptr;
   size_t wslab_bytes = 0;
   float* stage = nullptr;
@@ -270,6 +278,12 @@ typedef sdeo_handle_s Engine;
 struct Registry {
   Engine* e;
   size_t size = 0;
+  bool quant = true;          // matrices registered now belong to the UNet / ControlNet (fp8-eligible), not the VAE
+  void region(size_t off, int rows, int cols) {
+    if (!quant) return;
+    e->qindex[off] = (int)e->qregions.size();
+    e->qregions.push_back(QRegion{off, rows, cols, 0, 0});
+  }
   size_t take(size_t bytes) {
     const size_t off = align_up(size, 256);
     size = off + bytes;
@@ -287,11 +301,15 @@ struct Registry {
   void conv(const std::string& name, int cin, int cout, int k, int opad = -1) {
     const int ip = round8(cin);
     const int op = opad < 0 ? cout : opad;
-    add(name + ".weight", W_CONV, {cout, cin, k, k}, take((size_t)op * k * k * ip * 2), ip);
+    const size_t off = take((size_t)op * k * k * ip * 2);
+    add(name + ".weight", W_CONV, {cout, cin, k, k}, off, ip);
+    region(off, op, k * k * ip);
     add(name + ".bias", W_VEC, {cout}, take((size_t)op * 4));
   }
   void lin(const std::string& name, int cin, int cout, bool bias) {
-    add(name + ".weight", W_LINEAR, {cout, cin}, take((size_t)cout * cin * 2));
+    const size_t off = take((size_t)cout * cin * 2);
+    add(name + ".weight", W_LINEAR, {cout, cin}, off);
+    region(off, cout, cin);
     if (bias) add(name + ".bias", W_VEC, {cout}, take((size_t)cout * 4));
   }
   void vec(const std::string& name, int c) { add(name, W_VEC, {c}, take((size_t)c * 4)); }
@@ -324,10 +342,11 @@ static void reg_attn(Registry& r, const std::string& ns, const Blk& b, int ctx) 
   r.add(t + ".attn1.to_k.weight", W_LINEAR, {c, c}, qkv + (size_t)c * c * 2);
   r.add(t + ".attn1.to_v.weight", W_LINEAR, {c, c}, qkv + (size_t)2 * c * c * 2);
   r.lin(t + ".attn1.to_out.0", c, c, true);
-  r.lin(t + ".attn2.to_q", c, c, false);
+  r.add(t + ".attn2.to_q.weight", W_LINEAR, {c, c}, r.take((size_t)c * c * 2));      // raw: only the input of its LayerNorm fold
   // attn2: to_k and to_v stacked as one [2c][ctx] matrix (one GEMM per context)
   const size_t kv = r.take((size_t)2 * c * ctx * 2);
   r.e->named_off[t + ".attn2.to_kv"] = kv;
+  r.region(kv, 2 * c, ctx);
   r.add(t + ".attn2.to_k.weight", W_LINEAR, {c, ctx}, kv);
   r.add(t + ".attn2.to_v.weight", W_LINEAR, {c, ctx}, kv + (size_t)c * ctx * 2);
   r.lin(t + ".attn2.to_out.0", c, c, true);
@@ -346,6 +365,7 @@ static void reg_attn(Registry& r, const std::string& ns, const Blk& b, int ctx) 
     r.e->named_off[name + ".s"] = f.s_out;
     r.e->named_off[name + ".b"] = f.b_out;
     r.e->folds.push_back(f);
+    r.region(f.w_out, rows, c);        // the folded copy is what the network streams (the raw one is only the fold's input)
   };
   fold(t + ".attn1.qkv_ln", qkv, 3 * c, t + ".norm1", "");
   fold(t + ".attn2.q_ln", r.e->weights[r.e->windex.at(t + ".attn2.to_q.weight")].off, c, t + ".norm2", "");
@@ -374,6 +394,7 @@ static void reg_unet_like(Registry& r, const std::string& ns, const UPlan& p, co
   const size_t ew = r.take((size_t)total * emb * 2);
   const size_t eb = r.take((size_t)total * 4);
   r.e->named_off[ns + "emb_all.weight"] = ew;
+  r.region(ew, total, emb);
   r.e->named_off[ns + "emb_all.bias"] = eb;
   int row = 0;
   auto blocks = [&](const std::vector<Blk>& v) {
@@ -429,6 +450,7 @@ static void build_registry(Engine* e) {
   for (auto& hc : e->hconvs) r.conv(std::string(NS_CN) + hc.name, hc.cin, hc.cout, 3, round8(hc.cout));
   r.conv(std::string(NS_CN) + "middle_block_out.0", e->cplan.in_ch.back(), e->cplan.in_ch.back(), 1);
   // VAE decode path
+  r.quant = false;                   // the VAE stays fp16 (BASELINE configs[4])
   const std::string d = std::string(NS_VAE) + "decoder";
   r.conv(std::string(NS_VAE) + "post_quant_conv", c.vae_z_channels, c.vae_z_channels, 1, round8(c.vae_z_channels));
   int bin = 0;
@@ -511,6 +533,18 @@ struct Builder {
 
 
   void launch_conv(ConvGemm p, const float* scale_host, RowStats* stats = nullptr) {
+    if (e->weight_bits == 8 && p.M <= 512 && p.Cin % 64 == 0 && !p.ups && !p.bias_per_row && !conv_gemm_plan_is_halo(p)) {
+      // weight-bound shapes stream the fp8 copy of their matrix (same numbers: the fp16 copy holds the dequantised values); where
+      // the measured fp16 plan is a halo-reuse 3x3 kernel (activation-bound: M = 512 at long K) that kernel keeps the job
+      auto it = e->qindex.find((size_t)(reinterpret_cast<const char*>(p.w) - e->wslab));
+      if (it != e->qindex.end()) {
+        const QRegion& q = e->qregions[it->second];
+        if (q.cols == p.ldw && p.N <= q.rows) {
+          p.w = reinterpret_cast<const f16*>(e->q8slab + q.q_off);
+          p.wscale = reinterpret_cast<const float*>(e->q8slab + q.s_off);
+        }
+      }
+    }
     max_splitk = std::max(max_splitk, e->autotune ? conv_gemm_autotune_workspace_bytes(p) : conv_gemm_workspace_bytes(p));
     if (!dry && e->autotune) {
       ConvGemm q = p;
@@ -1173,6 +1207,7 @@ int sdeo_destroy(sdeo_handle h) {
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->wslab) (void)hipFree(h->wslab);
+  if (h->q8slab) (void)hipFree(h->q8slab);
   if (h->stage) (void)hipFree(h->stage);
   delete h;
   return 0;
@@ -1246,8 +1281,36 @@ int sdeo_finalize_weights(sdeo_handle h) {
                                 vec(f.gamma), vec(f.beta), vec(f.bias), f.rows, f.C, 0))
       return rc;
   }
+  if (h->weight_bits == 8) {
+    // fp8 pack: codes + per-row scales in a slab of their own; the fp16 copies become the dequantised values
+    if (!h->q8slab) {
+      size_t sz = 0;
+      for (QRegion& q : h->qregions) {
+        q.q_off = align_up(sz, 256); sz = q.q_off + (size_t)q.rows * q.cols;
+        q.s_off = align_up(sz, 256); sz = q.s_off + (size_t)q.rows * 4;
+      }
+      h->q8_bytes = align_up(sz, 256);
+      SDEO_HIP(hipMalloc((void**)&h->q8slab, h->q8_bytes));
+      h->device_bytes += h->q8_bytes;
+    }
+    for (const QRegion& q : h->qregions)
+      if (int rc = quantize_fp8_rows(reinterpret_cast<uint8_t*>(h->q8slab + q.q_off), reinterpret_cast<float*>(h->q8slab + q.s_off),
+                                     reinterpret_cast<f16*>(h->wslab + q.off), q.rows, q.cols, q.cols, q.cols, 0))
+        return rc;
+    for (const FoldJob& f : h->folds)          // the row sums of the LayerNorm fold must be those of the re-quantised matrix
+      if (int rc = row_sums_f16(reinterpret_cast<float*>(h->wslab + f.s_out), reinterpret_cast<const f16*>(h->wslab + f.w_out), f.rows, f.C, 0))
+        return rc;
+  }
   SDEO_HIP(hipDeviceSynchronize());
   h->finalized = true;
+  return 0;
+}
+
+int sdeo_set_weight_precision(sdeo_handle h, int bits) {
+  SDEO_CHECK(h, "sdeo_set_weight_precision: null handle");
+  SDEO_CHECK(bits == 16 || bits == 8, "sdeo_set_weight_precision: %d bits unsupported (16 or 8)", bits);
+  SDEO_CHECK(!h->finalized && !h->arena, "sdeo_set_weight_precision: call it before sdeo_finalize_weights / sdeo_configure");
+  h->weight_bits = bits;
   return 0;
 }
 
@@ -1257,8 +1320,9 @@ int sdeo_configure(sdeo_handle h, int n, int latent_h, int latent_w) {
   const int maxds = 1 << (h->cfg.num_levels - 1);
   SDEO_CHECK(latent_h >= maxds && latent_w >= maxds && latent_h % maxds == 0 && latent_w % maxds == 0,
              "sdeo_configure: latent %dx%d must be a positive multiple of %d", latent_h, latent_w, maxds);
+  SDEO_CHECK(h->weight_bits != 8 || h->q8slab, "sdeo_configure: fp8 weights are packed by sdeo_finalize_weights: call it first");
   free_configured(h);
-  h->device_bytes = h->wslab_bytes;
+  h->device_bytes = h->wslab_bytes + h->q8_bytes;
   h->N = n; h->lh = latent_h; h->lw = latent_w;
   const sdeo_config& c = h->cfg;
   const size_t px = (size_t)latent_h * latent_w;

@@ -34,6 +34,12 @@ int sdeo_debug_gemm_ln_f16(void* y, int ldy, const void* x, int ldx, const void*
                            const float* bias_folded, const float* stats, int stats_ld, int strips, int ln_c, int m, int n, int k, int act, float eps, void* workspace, size_t workspace_bytes, void* stream);
 int sdeo_debug_row_stats_f16(float* stats, int stats_ld, const void* x, int ldx, int rows, int c, void* stream);
 
+/* fp8 weight pack at op level (tests): quantise [rows][cols] fp16 in place to its dequantised values, codes -> q, scales -> scale;
+ * sdeo_debug_next_weights_fp8 makes the NEXT sdeo_gemm_f16 / sdeo_conv2d_nhwc_f16 call of this thread stream these codes
+ * (K-contiguous bytes, same [N][K] / KRSC layout) instead of its fp16 weight argument */
+int sdeo_debug_quantize_fp8_rows(void* w_f16_inout, void* q_out, float* scale_out, int rows, int cols, void* stream);
+void sdeo_debug_next_weights_fp8(const void* q, const float* scale);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,8 +48,27 @@ def krsc_from_oihw(w_oihw_f32, cin_pad=None):
     return y
 
 
-def conv2d_nhwc(x, w_krsc, bias=None, bias2=None, res=None, stride=1, upsample2x=False, act=0, scale=1.0):
-    """x (N,H,W,Cin) fp16; w_krsc (Cout,k,k,Cin) fp16; returns (N,Ho,Wo,Cout) fp16."""
+def quantize_fp8_rows(w):
+    """The library's fp8 weight pack on a [rows][cols] fp16 matrix: (codes uint8, scales fp32 [rows], dequantised fp16)."""
+    lib = _lib.load()
+    _need_cuda(w)
+    rows = w.shape[0]
+    wd = w.reshape(rows, -1).clone().contiguous()
+    q = torch.empty(wd.shape, dtype=torch.uint8, device=w.device)
+    sc = torch.empty((rows,), dtype=torch.float32, device=w.device)
+    check(lib.sdeo_debug_quantize_fp8_rows(ptr(wd), ptr(q), ptr(sc), _i(rows), _i(wd.shape[1]), cur_stream()), "quantize_fp8_rows")
+    return q.reshape(w.shape), sc, wd.reshape(w.shape)
+
+
+def _arm_fp8(lib, w8):
+    if w8 is not None:
+        q, sc = w8
+        assert q.dtype == torch.uint8 and q.is_contiguous() and sc.dtype == torch.float32
+        lib.sdeo_debug_next_weights_fp8(ptr(q), ptr(sc))
+
+
+def conv2d_nhwc(x, w_krsc, bias=None, bias2=None, res=None, stride=1, upsample2x=False, act=0, scale=1.0, w8=None):
+    """x (N,H,W,Cin) fp16; w_krsc (Cout,k,k,Cin) fp16; returns (N,Ho,Wo,Cout) fp16.  w8 = (codes, scales): stream the fp8 copy."""
     lib = _lib.load()
     _need_cuda(x, w_krsc)
     n, h, w, cin = x.shape
@@ -62,14 +81,16 @@ def conv2d_nhwc(x, w_krsc, bias=None, bias2=None, res=None, stride=1, upsample2x
     y = torch.empty((n, ho, wo, cout), dtype=torch.float16, device=x.device)
     args = (_i(n), _i(h), _i(w), _i(cin), _i(cout), _i(k), _i(stride), _i(int(upsample2x)))
     nb = lib.sdeo_conv2d_workspace_bytes(*args)
-    ws = _ws(nb, x.device)
+    ws = _ws(nb if w8 is None else max(nb, 64 << 20), x.device)
+    _arm_fp8(lib, w8)
     check(lib.sdeo_conv2d_nhwc_f16(ptr(y), ptr(x), ptr(w_krsc), ptr(bias), ptr(bias2), ptr(res), *args, _i(act), _f(scale),
                                    ptr(ws), C.c_size_t(ws.numel()), cur_stream()), "conv2d")
     return y
 
 
-def gemm(x, w, bias=None, res=None, act=0, scale=1.0, out_f32=False, bias_per_row=False):
-    """y[m][n] = x[m][k] . w[n][k]^T (+bias)(+res); x, w fp16 row-major (may be strided views with unit inner stride)."""
+def gemm(x, w, bias=None, res=None, act=0, scale=1.0, out_f32=False, bias_per_row=False, w8=None):
+    """y[m][n] = x[m][k] . w[n][k]^T (+bias)(+res); x, w fp16 row-major (may be strided views with unit inner stride).
+    w8 = (codes, scales): stream the fp8 copy of w instead."""
     lib = _lib.load()
     _need_cuda(x, w)
     m, k = x.shape
@@ -77,7 +98,8 @@ def gemm(x, w, bias=None, res=None, act=0, scale=1.0, out_f32=False, bias_per_ro
     assert k == k2 and x.stride(1) == 1 and w.stride(1) == 1
     y = torch.empty((m, n), dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
     nb = lib.sdeo_gemm_workspace_bytes(_i(m), _i(n), _i(k))
-    ws = _ws(nb, x.device)
+    ws = _ws(nb if w8 is None else max(nb, 64 << 20), x.device)
+    _arm_fp8(lib, w8)
     check(lib.sdeo_gemm_f16(ptr(y), _i(n), ptr(x), _i(x.stride(0)), ptr(w), _i(w.stride(0)), ptr(bias), ptr(res),
                             _i(res.stride(0) if res is not None else 0), _i(m), _i(n), _i(k), _i(act), _f(scale),
                             _i(int(out_f32)), _i(int(bias_per_row)), ptr(ws), C.c_size_t(ws.numel()), cur_stream()), "gemm")

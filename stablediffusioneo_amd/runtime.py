@@ -35,7 +35,10 @@ def make_config(ucfg: S.UNetConfig = S.UNET_SD15, vcfg: S.VAEConfig = S.VAE_SD15
 class SdeoRuntime:
     """create -> load_state_dict -> configure(n, h, w) -> controlnet / unet / apply_model / vae_decode."""
 
-    def __init__(self, ucfg: S.UNetConfig = S.UNET_SD15, vcfg: S.VAEConfig = S.VAE_SD15, device: Optional[torch.device] = None):
+    def __init__(self, ucfg: S.UNetConfig = S.UNET_SD15, vcfg: S.VAEConfig = S.VAE_SD15, device: Optional[torch.device] = None,
+                 weight_bits: int = 16):
+        """weight_bits = 8: the UNet / ControlNet matrices are packed to fp8 (OCP e4m3fn, per-output-channel power-of-two scale) when
+        the weights are finalised (BASELINE configs[4]; the reference's precision switch is `onnx2trt_static_plugin.py:40-42`)."""
         if not torch.cuda.is_available():
             raise _lib.SdeoError("SdeoRuntime needs a HIP device (there is no CPU fallback)")
         self.lib = _lib.load()
@@ -45,6 +48,9 @@ class SdeoRuntime:
         self.handle = C.c_void_p()
         self._cfg = make_config(ucfg, vcfg)
         check(self.lib.sdeo_create(C.byref(self._cfg), C.byref(self.handle)), "sdeo_create")
+        self.weight_bits = int(weight_bits)
+        if self.weight_bits != 16:
+            check(self.lib.sdeo_set_weight_precision(self.handle, C.c_int(self.weight_bits)), "set_weight_precision")
         self.n = self.h = self.w = 0
         self.n_controls = 13
         # bumped by every sdeo_configure: the library frees and re-plans its arenas / boundary buffers there, so a hipGraph

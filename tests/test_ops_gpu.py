@@ -355,6 +355,8 @@ ATTN_CASES = [  # (B, heads, Tq, Tk, d)
     # token counts of the benchmarked configurations: 64x64 latent (T = 4096, BASELINE configs[1]) and 96x96 (T = 9216 /
     # 2304, configs[3]); B = 1 and 2 heads keep the fp32 reference's score tensor small
     (1, 2, 4096, 4096, 40), (1, 2, 4096, 77, 40), (1, 2, 9216, 9216, 40), (1, 2, 2304, 2304, 80), (1, 2, 9216, 77, 40),
+    # ragged sizes on the long-sequence kernel (64 queries per wave, 128-key tiles): query / key tails inside a tile
+    (2, 3, 2100, 2100, 40), (1, 2, 2049, 1100, 40), (1, 1, 2304, 1024, 40), (1, 2, 2500, 1281, 40),
 ]
 
 
@@ -408,6 +410,23 @@ def test_attention_spike(ops):
     ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(v)).permute(0, 2, 1, 3).reshape(b, t, c)
     o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), hds)
     assert_close(o, ref, rtol=3e-3, atol=3e-3, what="attention spike")
+
+
+def test_attention_long_sequence_spikes(ops):
+    """the long-sequence kernel's deferred rescale: late dominant keys for queries of BOTH 32-query blocks of a wave, in
+    both key halves of a tile and in the last tile (the rescale must follow the pending P V of the same block)"""
+    b, hds, t, d = 1, 2, 2304, 40
+    c = hds * d
+    q = h16(randn((b, t, c), 530))
+    k = h16(randn((b, t, c), 531))
+    v = h16(randn((b, t, c), 532))
+    for qi, ki, amp in ((5, 2000, 4.0), (40, 2090, 5.0), (700, 1200, 4.0), (733, 2303, 6.0), (64, 70, 5.0), (2303, 1, 4.0)):
+        k[:, ki] = q[:, qi] * amp
+    sp = lambda x: x.float().reshape(b, t, hds, d).permute(0, 2, 1, 3)
+    sim = torch.einsum("bhid,bhjd->bhij", sp(q), sp(k)) * d ** -0.5
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(v)).permute(0, 2, 1, 3).reshape(b, t, c)
+    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), hds)
+    assert_close(o, ref, rtol=3e-3, atol=3e-3, what="long-sequence attention with spikes")
 
 
 # ------------------------------------------------------------------ sampler step / layout

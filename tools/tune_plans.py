@@ -20,6 +20,13 @@ rt = SdeoRuntime(S.UNET_SD15, S.VAE_SD15)
 for (n, h, w) in [(2, 64, 64), (2, 32, 32), (2, 96, 96), (4, 64, 64), (1, 64, 64), (2, 32, 48)]:
     rt.configure(n, h, w)
     print(f"configured n={n} {h}x{w}: {len(_lib.dump_tuned_plans(lib))} plans", flush=True)
+# fp8-weight plans (their own keys: epilogue-class slot + 4) of the configurations BASELINE configs[4] runs
+del rt
+rt8 = SdeoRuntime(S.UNET_SD15, S.VAE_SD15, weight_bits=8)
+rt8.load_synthetic_device(0)
+for (n, h, w) in [(2, 64, 64), (4, 64, 64)]:
+    rt8.configure(n, h, w)
+    print(f"configured fp8 n={n} {h}x{w}: {len(_lib.dump_tuned_plans(lib))} plans", flush=True)
 rows = sorted(_lib.dump_tuned_plans(lib))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 out = os.path.join(ROOT, "gpurun_out", "tuned_plans_gfx950.json")
