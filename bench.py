@@ -163,21 +163,30 @@ def main():
         img = model.decode_first_stage_uint8(z)
         return z, img
 
+    from stablediffusioneo_amd.sharding import unit_index
     for i in range(a.warmup):
-        one_image(rank + i * world, timed=False)
+        one_image(unit_index(rank, i, world), timed=False)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     zs = []
     for i in range(a.steps):
-        z, img = one_image(rank + i * world)      # image index -> rank: index % world == rank
+        z, img = one_image(unit_index(rank, i, world))      # unit (one batch of B images) u -> rank u % world
         zs.append(z)
-    zloc = torch.cat(zs).half()
+    zloc = torch.stack(zs).half()                 # (steps, B, 4, h, w): one row per unit, in shard_indices order
+    gather_ms = None
     if dist:
         from stablediffusioneo_amd.sharding import gather_latents
-        zall = gather_latents(zloc, world * a.steps * B)   # the only collective: final latents, 32 KiB / image
-        assert zall.shape[0] == world * a.steps * B
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        zall = gather_latents(zloc.reshape(a.steps, -1, h, w), world * a.steps)   # the only collective: final latents, 32 KiB / image
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        assert zall.shape[0] == world * a.steps
+        # unit u of the gathered tensor must be the unit this rank produced at step (u - rank) / world
+        for i in range(a.steps):
+            assert torch.equal(zall[unit_index(rank, i, world)].reshape(zloc[i].shape), zloc[i]), "gather order"
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -272,6 +281,8 @@ def main():
                        "guidance_scale": a.scale, "parallelism": f"dp{world} (image index -> rank, RCCL all_gather of final latents)",
                        "weights": "seeded synthetic (no checkpoint in the container)"},
         }
+        if gather_ms is not None:
+            out["latent_all_gather_ms"] = round(gather_ms, 3)      # the only collective of the job (rank 0's wall time, sync to sync)
         if golden_check:
             out["output_check"] = golden_check
         if roof:

@@ -107,8 +107,8 @@ int sdeo_cfg_ddim_step(float* x_prev, float* pred_x0, const float* x, const floa
  * (aperture 3, L1 gradient magnitude; called at canny2image_torch.py:33 on the HWC3 uint8 image) and the control preparation of
  * canny2image_torch.py:34-38.  img_hwc: device uint8 [h][w][c], c in 1..4.  edges (optional): device uint8 [h][w], 0 / 255.
  * control_chw (optional): device fp32 [3][h][w] = edges / 255 on three identical channels (HWC3 + /255 + HWC->CHW).
- * workspace: >= sdeo_canny_workspace_bytes(h, w) bytes of device memory.  Unlike the other entry points this one
- * synchronises `stream` (hysteresis is iterated to a fixed point) and is not graph-capturable. */
+ * workspace: >= sdeo_canny_workspace_bytes(h, w) bytes of device memory, 4-byte aligned.  Asynchronous on `stream` and
+ * hipGraph-capturable like every other entry point (hysteresis is a union-find labelling, not a host-driven iteration). */
 size_t sdeo_canny_workspace_bytes(int h, int w);
 int sdeo_canny_u8(const uint8_t* img_hwc, int h, int w, int c, float low_threshold, float high_threshold, uint8_t* edges,
                   float* control_chw, void* workspace, size_t workspace_bytes, void* stream);

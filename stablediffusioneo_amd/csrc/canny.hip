@@ -3,11 +3,12 @@
 // OpenCV itself (pinned opencv-contrib-python 4.3.0.36, `environment.yaml:15`) is not in the reference tree; the integer
 // algorithm of its imgproc/canny.cpp is restated in oracle/canny_oracle.py and these kernels are bit-exact to that oracle.
 //
-// HBM-bound byte work, four small kernels over the image (no reshaping into GEMMs):
+// HBM-bound byte work, six small kernels over the image (no reshaping into GEMMs, no host loop: hipGraph-capturable):
 //   gradient   3x3 Sobel per channel (replicated border), |dx| + |dy|, channel of the largest magnitude per pixel
 //   nms        fixed-point sector test (TG22 = 13573), thresholds -> map {0 candidate, 1 no edge, 2 edge}
-//   hysteresis 32x32 tiles (+1 halo) iterate to a local fixed point in LDS; the launch is repeated until no tile changes
-//              (edges are the 8-connected components of candidates that contain an edge: order-independent, deterministic)
+//   hysteresis the 8-connected components of {candidate, edge} pixels by union-find on pixel indices (init / merge / mark the
+//              components that hold an edge): a candidate is an edge iff its component holds one -- order-independent,
+//              deterministic, and the same fixed point OpenCV's stack-based flood reaches
 //   finalize   255 / 0 (+ optional fp32 control tensor [3][H][W] = edges / 255, `canny2image_torch.py:34-38`)
 #include "kernels.h"
 
@@ -65,39 +66,64 @@ __global__ __launch_bounds__(256) void canny_nms_kernel(const short* __restrict_
   map[o] = r;
 }
 
-__global__ __launch_bounds__(1024) void canny_hyst_kernel(uint8_t* __restrict__ map, int H, int W, int* __restrict__ changed) {
-  __shared__ uint8_t t[34][36];
-  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
-  for (int i = threadIdx.x; i < 34 * 34; i += 1024) {
-    const int ty = i / 34, tx = i - ty * 34;
-    const int gy = y0 + ty - 1, gx = x0 + tx - 1;
-    t[ty][tx] = (gy < 0 || gy >= H || gx < 0 || gx >= W) ? 1 : map[(size_t)gy * W + gx];
-  }
-  __syncthreads();
-  const int gx = x0 + lx, gy = y0 + ly;
-  const bool inside = gx < W && gy < H;
-  bool mine = false;
+// ---- hysteresis without a host loop: a candidate pixel (map 0) becomes an edge when its 8-connected component of
+// {candidates, strong edges} contains a strong edge (map 2) -- exactly the fixed point cv2.Canny's stack-based flood reaches.
+// Components by union-find on pixel indices (parents only ever decrease: atomicMin), three launches, no iteration count that
+// depends on the image, nothing for the host to read back: the entry point is hipGraph-capturable.
+// Reads of a parent that race with an atomicMin may return an older parent: still an element of the same set with a smaller or
+// equal index, so `find` terminates and `unite` (which re-validates through the value its atomic returns) stays correct.
+__device__ __forceinline__ int uf_find(const int* L, int i) {
   for (;;) {
-    bool ch = false;
-    if (inside && t[ly + 1][lx + 1] == 0) {
-      // monotone 0 -> 2 updates: a neighbour read that races with its writer sees either value, both are valid states
-      const bool s = t[ly][lx] == 2 || t[ly][lx + 1] == 2 || t[ly][lx + 2] == 2 || t[ly + 1][lx] == 2 || t[ly + 1][lx + 2] == 2 ||
-                     t[ly + 2][lx] == 2 || t[ly + 2][lx + 1] == 2 || t[ly + 2][lx + 2] == 2;
-      if (s) { t[ly + 1][lx + 1] = 2; ch = true; mine = true; }
-    }
-    if (!__syncthreads_or(ch)) break;
+    const int pnt = __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (pnt == i) return i;
+    i = pnt;
   }
-  if (mine) {
-    map[(size_t)gy * W + gx] = 2;
-    *changed = 1;
+}
+__device__ __forceinline__ void uf_unite(int* L, int a, int b) {
+  for (;;) {
+    a = uf_find(L, a);
+    b = uf_find(L, b);
+    if (a == b) return;
+    if (a > b) { const int t = a; a = b; b = t; }                  // a < b: hang b under a
+    const int old = atomicMin(L + b, a);
+    if (old == b) return;                                           // b was still a root: done
+    b = old;                                                        // somebody re-parented b meanwhile: merge a with that parent
   }
 }
 
-__global__ __launch_bounds__(256) void canny_final_kernel(const uint8_t* __restrict__ map, int64_t n, uint8_t* __restrict__ edges,
+__global__ __launch_bounds__(256) void canny_label_init_kernel(const uint8_t* __restrict__ map, int64_t n, int* __restrict__ L,
+                                                               int* __restrict__ strong) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    L[i] = map[i] != 1 ? (int)i : -1;
+    strong[i] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void canny_label_merge_kernel(const uint8_t* __restrict__ map, int H, int W, int* __restrict__ L) {
+  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (x >= W || y >= H) return;
+  const int i = y * W + x;
+  if (map[i] == 1) return;
+  // the four neighbours that precede the pixel in raster order: every adjacent pair is visited once
+  if (x > 0 && map[i - 1] != 1) uf_unite(L, i, i - 1);
+  if (y > 0) {
+    if (map[i - W] != 1) uf_unite(L, i, i - W);
+    if (x > 0 && map[i - W - 1] != 1) uf_unite(L, i, i - W - 1);
+    if (x + 1 < W && map[i - W + 1] != 1) uf_unite(L, i, i - W + 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void canny_label_strong_kernel(const uint8_t* __restrict__ map, int64_t n, const int* __restrict__ L,
+                                                                 int* __restrict__ strong) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    if (map[i] == 2) strong[uf_find(L, (int)i)] = 1;               // benign race: every writer stores 1
+}
+
+__global__ __launch_bounds__(256) void canny_final_kernel(const uint8_t* __restrict__ map, int64_t n, const int* __restrict__ L,
+                                                          const int* __restrict__ strong, uint8_t* __restrict__ edges,
                                                           float* __restrict__ control) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const bool e = map[i] == 2;
+    const bool e = map[i] != 1 && strong[uf_find(L, (int)i)] != 0;
     if (edges) edges[i] = e ? 255 : 0;
     if (control) {
       const float v = e ? 1.0f : 0.0f;             // 255 / 255
@@ -106,42 +132,32 @@ __global__ __launch_bounds__(256) void canny_final_kernel(const uint8_t* __restr
   }
 }
 
-size_t canny_workspace_bytes(int H, int W) { return (size_t)H * W * 7 + 512; }
+size_t canny_workspace_bytes(int H, int W) { return (size_t)H * W * 15 + 512; }
 
 int canny_u8(const uint8_t* img, int H, int W, int C, float low_threshold, float high_threshold, uint8_t* edges, float* control,
              void* workspace, size_t workspace_bytes, hipStream_t stream) {
   SDEO_CHECK(img && (edges || control) && workspace, "canny: null argument");
-  SDEO_CHECK(H >= 1 && W >= 1 && C >= 1 && C <= 4, "canny: bad image %dx%dx%d (1..4 channels)", H, W, C);
+  SDEO_CHECK(H >= 1 && W >= 1 && C >= 1 && C <= 4 && (int64_t)H * W < (1ll << 31), "canny: bad image %dx%dx%d (1..4 channels)", H, W, C);
   SDEO_CHECK(workspace_bytes >= canny_workspace_bytes(H, W), "canny: workspace too small (%zu < %zu)", workspace_bytes,
              canny_workspace_bytes(H, W));
+  SDEO_CHECK((reinterpret_cast<uintptr_t>(workspace) & 3) == 0, "canny: workspace must be 4-byte aligned");
   int low = (int)floorf(low_threshold), high = (int)floorf(high_threshold);
   if (low > high) { const int t = low; low = high; high = t; }
   const size_t n = (size_t)H * W;
   char* ws = static_cast<char*>(workspace);
-  int* changed = reinterpret_cast<int*>(ws);
-  short* dx = reinterpret_cast<short*>(ws + 512);
+  int* L = reinterpret_cast<int*>(ws + 512);                // labels / strong flags first: 4-byte aligned
+  int* strong = L + n;
+  short* dx = reinterpret_cast<short*>(strong + n);
   short* dy = dx + n;
   short* mag = dy + n;
   uint8_t* map = reinterpret_cast<uint8_t*>(mag + n);
-  const dim3 g8(cdiv(W, 32), cdiv(H, 8)), g32(cdiv(W, 32), cdiv(H, 32));
+  const dim3 g8(cdiv(W, 32), cdiv(H, 8));
   hipLaunchKernelGGL(canny_grad_kernel, g8, dim3(256), 0, stream, img, H, W, C, dx, dy, mag);
   hipLaunchKernelGGL(canny_nms_kernel, g8, dim3(256), 0, stream, dx, dy, mag, H, W, low, high, map);
-  SDEO_HIP(hipGetLastError());
-  // hysteresis to a global fixed point: every launch settles each tile; a chain that crosses a tile boundary needs one more
-  // launch per crossing (it may re-enter a tile many times), so the loop runs until a launch changes nothing.  Every launch
-  // that continues the loop turns at least one candidate into an edge: n + 1 launches is a true upper bound.  The flag read
-  // makes this entry point synchronising.
-  const size_t max_iter = n + 1;
-  for (size_t it = 0; it < max_iter; ++it) {
-    int h_changed = 0;
-    SDEO_HIP(hipMemsetAsync(changed, 0, sizeof(int), stream));
-    hipLaunchKernelGGL(canny_hyst_kernel, g32, dim3(1024), 0, stream, map, H, W, changed);
-    SDEO_HIP(hipGetLastError());
-    SDEO_HIP(hipMemcpyAsync(&h_changed, changed, sizeof(int), hipMemcpyDeviceToHost, stream));
-    SDEO_HIP(hipStreamSynchronize(stream));
-    if (!h_changed) break;
-  }
-  hipLaunchKernelGGL(canny_final_kernel, grid_for((int64_t)n), dim3(256), 0, stream, map, (int64_t)n, edges, control);
+  hipLaunchKernelGGL(canny_label_init_kernel, grid_for((int64_t)n), dim3(256), 0, stream, map, (int64_t)n, L, strong);
+  hipLaunchKernelGGL(canny_label_merge_kernel, g8, dim3(256), 0, stream, map, H, W, L);
+  hipLaunchKernelGGL(canny_label_strong_kernel, grid_for((int64_t)n), dim3(256), 0, stream, map, (int64_t)n, L, strong);
+  hipLaunchKernelGGL(canny_final_kernel, grid_for((int64_t)n), dim3(256), 0, stream, map, (int64_t)n, L, strong, edges, control);
   SDEO_HIP(hipGetLastError());
   return 0;
 }

@@ -129,7 +129,7 @@ int row_sums_f16(float* s_out, const f16* w, int rows, int C, hipStream_t stream
 int embed_tokens(f16* out, const int32_t* ids, const f16* tok_emb, const f16* pos_emb, int B, int T, int W, int vocab,
                  hipStream_t stream);
 // cv2.Canny(img, low, high) (aperture 3, L1 magnitude) on an HWC uint8 image of 1..4 channels -> edges [H][W] uint8 0 / 255 and / or
-// control [3][H][W] fp32 = edges / 255.  Synchronises `stream` (hysteresis runs to a fixed point).  csrc/canny.hip
+// control [3][H][W] fp32 = edges / 255.  Asynchronous, capturable (hysteresis = union-find labelling).  csrc/canny.hip
 size_t canny_workspace_bytes(int H, int W);
 int canny_u8(const uint8_t* img, int H, int W, int C, float low_threshold, float high_threshold, uint8_t* edges, float* control,
              void* workspace, size_t workspace_bytes, hipStream_t stream);

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void resize_area_kernel(uint8_t* __restrict__ 
                                                           int dw, const int* __restrict__ xstart, const int* __restrict__ xidx,
                                                           const float* __restrict__ xw, const int* __restrict__ ystart,
                                                           const int* __restrict__ yidx, const float* __restrict__ yw) {
+#pragma clang fp contract(off)      // OpenCV's loop multiplies, rounds, then adds: a fused multiply-add would round once
   const int64_t total = (int64_t)dh * dw * c;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int ch = (int)(i % c);
@@ -55,9 +56,9 @@ __global__ __launch_bounds__(256) void resize_area_kernel(uint8_t* __restrict__ 
     for (int yk = ystart[dy]; yk < ystart[dy + 1]; ++yk) {
       const uint8_t* row = src + (size_t)yidx[yk] * w * c + ch;
       float buf = 0.f;
-      for (int xk = xstart[dx]; xk < xstart[dx + 1]; ++xk) buf = __fadd_rn(buf, __fmul_rn((float)row[(size_t)xidx[xk] * c], xw[xk]));
-      const float t = __fmul_rn(buf, yw[yk]);
-      sum = yk == ystart[dy] ? t : __fadd_rn(sum, t);
+      for (int xk = xstart[dx]; xk < xstart[dx + 1]; ++xk) buf = buf + (float)row[(size_t)xidx[xk] * c] * xw[xk];
+      const float t = buf * yw[yk];
+      sum = yk == ystart[dy] ? t : sum + t;
     }
     const float r = rintf(sum);
     dst[i] = (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));

@@ -17,6 +17,12 @@ def shard_indices(total: int, rank: int, world: int) -> List[int]:
     return list(range(rank, total, world))
 
 
+def unit_index(rank: int, step: int, world: int) -> int:
+    """Index of the work unit (one image, or one batch of images) rank `rank` processes at its `step`-th step: the inverse of
+    shard_indices -- shard_indices(total, rank, world)[step] == unit_index(rank, step, world).  bench.py seeds its inputs with it."""
+    return rank + step * world
+
+
 def gather_latents(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
     """local: (n_local, C, h, w) latents of shard_indices(total, rank, world) in that order.
     Returns (total, C, h, w) in image-index order on every rank.  Ragged shards (total % world != 0) are padded

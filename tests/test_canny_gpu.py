@@ -94,3 +94,41 @@ def test_process_uses_the_hip_detector():
     hk.apply_canny = lambda im, lo, hi: O.canny(im, lo, hi)   # the reference-style numpy-in / numpy-out branch
     b = hk.process(img, "a bird", "best quality", "lowres", 1, 64, 2, False, 1.0, 9.0, 7, 0.0, 100, 200)
     np.testing.assert_array_equal(a[0], b[0])
+
+
+def test_canny_is_graph_capturable():
+    """`sdeo_canny_u8` neither synchronises nor reads anything back (hysteresis = union-find labelling): captured once in a hipGraph,
+    replayed on new pixels in the same buffers (the stage `compute_score.py:47-64` times sits inside process())"""
+    import ctypes as C
+    from oracle import canny_oracle as O
+    from stablediffusioneo_amd import _lib
+    lib = _lib.load()
+    lib.sdeo_canny_workspace_bytes.restype = C.c_size_t
+    H, W = 160, 224
+    rng = np.random.default_rng(5)
+    from scipy import ndimage
+    imgs = [((ndimage.uniform_filter(rng.integers(0, 256, (H, W, 3)).astype(np.float32), size=(5, 5, 1)) - 96) * 4).clip(0, 255).astype(np.uint8)
+            for _ in range(3)]
+    src = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    edges = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    nb = int(lib.sdeo_canny_workspace_bytes(C.c_int(H), C.c_int(W)))
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+
+    def run():
+        _lib.check(lib.sdeo_canny_u8(C.c_void_p(src.data_ptr()), C.c_int(H), C.c_int(W), C.c_int(3), C.c_float(60), C.c_float(150),
+                                     C.c_void_p(edges.data_ptr()), None, C.c_void_p(ws.data_ptr()), C.c_size_t(nb),
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "canny")
+
+    src.copy_(torch.from_numpy(imgs[0]))
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        run()                                   # eager warm-up on the capture stream
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        run()
+    for im in imgs:
+        src.copy_(torch.from_numpy(im))
+        g.replay()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(edges.cpu().numpy(), O.canny(im, 60, 150))

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from stablediffusioneo_amd.sharding import gather_latents, shard_indices
+from stablediffusioneo_amd.sharding import gather_latents, shard_indices, unit_index
 
 
 def _free_port():
@@ -53,6 +53,44 @@ def test_gloo_world2_image_sharding(total):
     assert all(ok for _, ok, _ in res)
     seen = sorted(i for _, _, idx in res for i in idx)
     assert seen == list(range(total))          # every image exactly once, no overlap
+
+
+def _bench_worker(rank, world, port, steps, batch, q):
+    """the N > 1 data flow of bench.py, on CPU tensors: every rank runs `steps` units of `batch` images, unit index from
+    unit_index(rank, step, world), one all-gather of the (steps, batch*4, h, w) latents at the end"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        zs = []
+        for i in range(steps):
+            u = unit_index(rank, i, world)
+            zs.append(torch.stack([fake_latent(u * batch + j) for j in range(batch)]))
+        zloc = torch.stack(zs)
+        zall = gather_latents(zloc.reshape(steps, -1, 8, 8), world * steps).reshape(world * steps, batch, 4, 8, 8)
+        ref = torch.stack([torch.stack([fake_latent(u * batch + j) for j in range(batch)]) for u in range(world * steps)])
+        q.put((rank, bool(torch.equal(zall, ref)), [unit_index(rank, i, world) for i in range(steps)]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("steps,batch", [(3, 1), (2, 2), (1, 1)])
+def test_bench_unit_mapping_and_gather_order(steps, batch):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, steps, batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    for rank, _, units in res:
+        assert units == shard_indices(world * steps, rank, world)      # bench's mapping IS the sharding rule
+    assert sorted(u for _, _, units in res for u in units) == list(range(world * steps))
 
 
 def test_shard_indices_properties():
