@@ -43,13 +43,16 @@ struct AP {
   int causal;        // 1: key j is visible to query t only when j <= t (CLIP text transformer)
 };
 
+struct AP2 { AP k[2]; };
+
 // KS = 1: four waves, each owning 32 queries and walking all keys.  KS = 2 ("key split"): eight waves, the two waves of a
 // pair own the same 32 queries and each takes one 32-key half of every staged tile, so the serial per-tile chain
 // (QK^T -> max -> exp -> PV) per wave halves and twice as many waves hide it; the two partial (m, l, O) states are merged
 // through LDS at the end.  Reduction order is fixed (half 0 then half 1), so results stay deterministic.
 template <int D16, int KS>
 __global__ __launch_bounds__(256 * KS, (KS == 2 ? (D16 <= 4 ? 4 : 2) : (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))))
-void attention_kernel(const AP p) {
+void attention_kernel(const AP2 pp) {
+  const AP& p = pp.k[blockIdx.y];      // pair launch: two problems of one shape, see KP2 in conv_inl.h
   constexpr int NT = 256 * KS;                               // threads per workgroup
   constexpr int NKB = 2 / KS;                                // 32-key blocks of a tile each wave handles
   constexpr int DT = (D16 + 1) / 2;                          // 32-row tiles of O^T
@@ -326,7 +329,8 @@ void attention_kernel(const AP p) {
 }
 
 template <int D16, int KS>
-static int launch_attn_ks(const AP& ap, int B, hipStream_t stream) {
+static int launch_attn_ks(const AP2& ap2, int count, int B, hipStream_t stream) {
+  const AP& ap = ap2.k[0];
   constexpr int DT = (D16 + 1) / 2;
   constexpr int KROW = D16 * 32 + ((D16 * 2) % 2 == 0 ? 16 : 0);
   constexpr int stage2 = 2 * (64 * KROW + 64 * attn_vrow(DT));
@@ -338,8 +342,8 @@ static int launch_attn_ks(const AP& ap, int B, hipStream_t stream) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_done = true;
   }
-  dim3 grid(cdiv(ap.Tq, 128) * B * ap.H);
-  hipLaunchKernelGGL((attention_kernel<D16, KS>), grid, dim3(256 * KS), smem, stream, ap);
+  dim3 grid(cdiv(ap.Tq, 128) * B * ap.H, count);
+  hipLaunchKernelGGL((attention_kernel<D16, KS>), grid, dim3(256 * KS), smem, stream, ap2);
   SDEO_HIP(hipGetLastError());
   return 0;
 }
@@ -353,38 +357,67 @@ static int attn_key_split(const AP& ap, int d16) {
 }
 
 template <int D16>
-static int launch_attn(const AP& ap, int B, hipStream_t stream) {
+static int launch_attn(const AP2& ap, int count, int B, hipStream_t stream) {
   if constexpr (D16 <= 5) {
-    if (attn_key_split(ap, D16) == 2) return launch_attn_ks<D16, 2>(ap, B, stream);
+    if (attn_key_split(ap.k[0], D16) == 2) return launch_attn_ks<D16, 2>(ap, count, B, stream);
   }
-  return launch_attn_ks<D16, 1>(ap, B, stream);
+  return launch_attn_ks<D16, 1>(ap, count, B, stream);
+}
+
+static int attn_prepare(AP& ap, const AttnArgs& a) {
+  SDEO_CHECK(a.o && a.q && a.k && a.v, "attention: null operand");
+  SDEO_CHECK(a.B > 0 && a.H > 0 && a.Tq > 0 && a.Tk > 0 && a.TkS >= a.Tk && a.TkSv >= a.Tk,
+             "attention: bad sizes B=%d H=%d Tq=%d Tk=%d TkS=%d TkSv=%d", a.B, a.H, a.Tq, a.Tk, a.TkS, a.TkSv);
+  SDEO_CHECK(a.d % 8 == 0 && a.d >= 8 && a.d <= 160, "attention: head dim %d unsupported (multiple of 8, <= 160)", a.d);
+  SDEO_CHECK(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 4 == 0,
+             "attention: strides must keep 16-byte alignment (ldq=%d ldk=%d ldv=%d ldo=%d)", a.ldq, a.ldk, a.ldv, a.ldo);
+  SDEO_CHECK((reinterpret_cast<uintptr_t>(a.q) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.k) & 15) == 0 &&
+                 (reinterpret_cast<uintptr_t>(a.v) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.o) & 7) == 0,
+             "attention: operands must be 16-byte aligned");
+  SDEO_CHECK(!a.causal || a.Tq == a.Tk, "attention: causal needs Tq == Tk (got %d, %d)", a.Tq, a.Tk);
+  ap = AP{a.o, a.q, a.k, a.v, a.ldo, a.ldq, a.ldk, a.ldv, a.H, a.Tq, a.Tk, a.TkS, a.TkSv, a.d, a.scale * 1.4426950408889634f, a.causal ? 1 : 0};
+  return 0;
+}
+
+static int attn_dispatch(const AP2& ap, int count, int B, hipStream_t stream) {
+  const int d = ap.k[0].d;
+  switch (cdiv(d, 16)) {
+    case 1: return launch_attn<1>(ap, count, B, stream);
+    case 2: return launch_attn<2>(ap, count, B, stream);
+    case 3: return launch_attn<3>(ap, count, B, stream);
+    case 4: return launch_attn<4>(ap, count, B, stream);
+    case 5: return launch_attn<5>(ap, count, B, stream);
+    case 6: return launch_attn<6>(ap, count, B, stream);
+    case 8: return launch_attn<8>(ap, count, B, stream);
+    case 10: return launch_attn<10>(ap, count, B, stream);
+    default: return fail("attention: head dim %d not instantiated", d);
+  }
+}
+
+int attention(const AttnArgs& a, hipStream_t stream) {
+  AP2 ap{};
+  if (int rc = attn_prepare(ap.k[0], a)) return rc;
+  return attn_dispatch(ap, 1, a.B, stream);
+}
+
+bool attention_can_pair(const AttnArgs& a, const AttnArgs& b) {
+  return a.B == b.B && a.H == b.H && a.Tq == b.Tq && a.Tk == b.Tk && a.d == b.d && a.causal == b.causal;
+}
+
+int attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t stream) {
+  if (!attention_can_pair(a, b)) {
+    if (int rc = attention(a, stream)) return rc;
+    return attention(b, stream);
+  }
+  AP2 ap{};
+  if (int rc = attn_prepare(ap.k[0], a)) return rc;
+  if (int rc = attn_prepare(ap.k[1], b)) return rc;
+  return attn_dispatch(ap, 2, a.B, stream);
 }
 
 int attention(f16* o, int ldo, const f16* q, int ldq, const f16* k, int ldk, const f16* v, int ldv, int B, int H,
               int Tq, int Tk, int TkS, int TkSv, int d, float scale, hipStream_t stream, int causal) {
-  SDEO_CHECK(o && q && k && v, "attention: null operand");
-  SDEO_CHECK(B > 0 && H > 0 && Tq > 0 && Tk > 0 && TkS >= Tk && TkSv >= Tk, "attention: bad sizes B=%d H=%d Tq=%d Tk=%d TkS=%d TkSv=%d", B,
-             H, Tq, Tk, TkS, TkSv);
-  SDEO_CHECK(d % 8 == 0 && d >= 8 && d <= 160, "attention: head dim %d unsupported (multiple of 8, <= 160)", d);
-  SDEO_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0,
-             "attention: strides must keep 16-byte alignment (ldq=%d ldk=%d ldv=%d ldo=%d)", ldq, ldk, ldv, ldo);
-  SDEO_CHECK((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (reinterpret_cast<uintptr_t>(k) & 15) == 0 &&
-                 (reinterpret_cast<uintptr_t>(v) & 15) == 0 && (reinterpret_cast<uintptr_t>(o) & 7) == 0,
-             "attention: operands must be 16-byte aligned");
-  SDEO_CHECK(!causal || Tq == Tk, "attention: causal needs Tq == Tk (got %d, %d)", Tq, Tk);
-  AP ap{o, q, k, v, ldo, ldq, ldk, ldv, H, Tq, Tk, TkS, TkSv, d, scale * 1.4426950408889634f, causal ? 1 : 0};
-  const int d16 = cdiv(d, 16);
-  switch (d16) {
-    case 1: return launch_attn<1>(ap, B, stream);
-    case 2: return launch_attn<2>(ap, B, stream);
-    case 3: return launch_attn<3>(ap, B, stream);
-    case 4: return launch_attn<4>(ap, B, stream);
-    case 5: return launch_attn<5>(ap, B, stream);
-    case 6: return launch_attn<6>(ap, B, stream);
-    case 8: return launch_attn<8>(ap, B, stream);
-    case 10: return launch_attn<10>(ap, B, stream);
-    default: return fail("attention: head dim %d not instantiated", d);
-  }
+  return attention(AttnArgs{o, q, k, v, ldo, ldq, ldk, ldv, B, H, Tq, Tk, TkS, TkSv, d, scale, causal}, stream);
 }
 
 }  // namespace sdeo

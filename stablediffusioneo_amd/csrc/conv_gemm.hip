@@ -48,7 +48,8 @@ namespace sdeo {
 // MFMA waves widen each 8-byte fragment to fp16 in registers (v_cvt_scalef32_pk_f16_fp8, exact) right before its MFMAs.
 // The activations, the accumulation and the epilogue are those of the fp16 kernel; what changes is the bytes streamed.
 template <int BM, int BN, int STAGES, bool UPS, bool WS, bool W8 = false>
-__global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP p) {
+__global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2 pp) {
+  const KP& p = pp.k[blockIdx.y];
   constexpr int BK = 64, RPP = 32;
   constexpr int WRPP = W8 ? 64 : 32;                           // weight rows per DMA pass
   constexpr int XP = BM / RPP, WP = (BN + WRPP - 1) / WRPP, L = XP + WP;     // DMA instructions per loading thread per stage
@@ -400,7 +401,8 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP 
 // fallback kernel: register-staged double buffer (any Cin % 8 == 0)
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int BK, bool GENERIC>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const KP p) {
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const KP2 pp) {
+  const KP& p = pp.k[blockIdx.y];
   constexpr int CPR = BK / 8;         // 16-byte chunks per tile row
   constexpr int RPP = 256 / CPR;      // tile rows covered per pass of the 256 threads
   constexpr int XP = BM / RPP;        // passes for the activation tile
@@ -555,7 +557,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KP p) {
 }
 
 // split-K: sum the fp32 partial slabs and apply the epilogue. One thread per 4 output channels.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const KP p) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const KP2 pp) {
+  const KP& p = pp.k[blockIdx.y];
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int n4 = p.N / 4;
   if (idx >= (int64_t)p.M * n4) return;
@@ -762,12 +765,12 @@ size_t conv_gemm_workspace_bytes(const ConvGemm& p) {
 const char* conv_gemm_kernel_name(const ConvGemm& p) { return kTiles[make_plan(p).tile].name; }
 
 template <typename K>
-static int launch_k(K kernel, int smem, bool* attr_done, const KP& kp, int tiles, hipStream_t stream, int threads = 256) {
+static int launch_k(K kernel, int smem, bool* attr_done, const KP2& kp, int count, int tiles, hipStream_t stream, int threads = 256) {
   if (!*attr_done) {
     SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     *attr_done = true;
   }
-  dim3 grid(tiles, 1, kp.splitk);
+  dim3 grid(tiles, count, kp.k[0].splitk);
   hipLaunchKernelGGL(kernel, grid, dim3(threads), smem, stream, kp);
   SDEO_HIP(hipGetLastError());
   return 0;
@@ -781,24 +784,25 @@ static bool use_ws() {
 
 // fp8-weight instantiations: wave-specialised only, no folded Upsample (the weight-bound convs have neither)
 template <int BM, int BN, int ST>
-static int launch_dma_w8(const KP& kp, int tiles, hipStream_t stream) {
+static int launch_dma_w8(const KP2& kp, int count, int tiles, hipStream_t stream) {
   static bool done = false;
   constexpr int smem = ST * (BM * 128 + (BN + 63) / 64 * 4096) + BM * 8;
-  return launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, true, true>, smem, &done, kp, tiles, stream, 512);
+  return launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, true, true>, smem, &done, kp, count, tiles, stream, 512);
 }
 
 template <int BM, int BN, int ST>
-static int launch_dma(int ups, const KP& kp, int tiles, hipStream_t stream) {
+static int launch_dma(int ups, const KP2& kp, int count, int tiles, hipStream_t stream) {
   static bool done[4] = {false, false, false, false};
   constexpr int smem = ST * (BM + BN) * 128 + BM * 8;      // ring + the LayerNorm row scalars (conv_gemm_dma_kernel: lnsm)
   if (use_ws())
-    return ups ? launch_k(&conv_gemm_dma_kernel<BM, BN, ST, true, true>, smem, &done[3], kp, tiles, stream, 512)
-               : launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, true>, smem, &done[2], kp, tiles, stream, 512);
-  return ups ? launch_k(&conv_gemm_dma_kernel<BM, BN, ST, true, false>, smem, &done[1], kp, tiles, stream)
-             : launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, false>, smem, &done[0], kp, tiles, stream);
+    return ups ? launch_k(&conv_gemm_dma_kernel<BM, BN, ST, true, true>, smem, &done[3], kp, count, tiles, stream, 512)
+               : launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, true>, smem, &done[2], kp, count, tiles, stream, 512);
+  return ups ? launch_k(&conv_gemm_dma_kernel<BM, BN, ST, true, false>, smem, &done[1], kp, count, tiles, stream)
+             : launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, false>, smem, &done[0], kp, count, tiles, stream);
 }
 
-int conv_gemm(const ConvGemm& p, hipStream_t stream) {
+// argument checks + plan + kernel parameters of one problem
+static int prepare(const ConvGemm& p, Plan& pl, KP& kp) {
   SDEO_CHECK(p.x && p.w && (p.y || p.y32), "conv_gemm: null operand");
   SDEO_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "conv_gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
   SDEO_CHECK(p.N % 4 == 0, "conv_gemm: N=%d must be a multiple of 4", p.N);
@@ -824,10 +828,10 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
   if (p.wscale)
     SDEO_CHECK(p.Cin % 64 == 0 && !p.ups && p.ldw % 16 == 0 && !p.bias_per_row,
                "conv_gemm: fp8 weights need Cin %% 64 == 0 (Cin=%d), no folded upsample and 16-byte aligned rows (ldw=%d bytes)", p.Cin, p.ldw);
-  const Plan pl = make_plan(p);
+  pl = make_plan(p);
   SDEO_CHECK(!p.wscale || (tile_has_w8(pl.tile) && kTiles[pl.tile].kind == TK_DMA), "conv_gemm: no fp8-weight plan for this shape");
   SDEO_CHECK(p.act != 3 || (pl.splitk == 1 && (kTiles[pl.tile].bn / 2) % 32 == 0), "conv_gemm: no GEGLU-capable plan");
-  KP kp{};
+  kp = KP{};
   kp.x = p.x; kp.w = p.w; kp.y = p.y; kp.y32 = p.y32; kp.bias = p.bias; kp.bias2 = p.bias2; kp.res = p.res;
   kp.ws = p.workspace;
   kp.M = p.M; kp.N = p.N; kp.K = p.K;
@@ -871,49 +875,80 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
     SDEO_CHECK(p.workspace && p.workspace_bytes >= need, "conv_gemm: split-K workspace too small (%zu < %zu)",
                p.workspace_bytes, need);
   }
+  if (kTiles[pl.tile].kind == TK_HALO) SDEO_CHECK(halo_ok(p, kTiles[pl.tile]), "conv_gemm: halo plan on an ineligible problem");
+  return 0;
+}
+
+// launch `count` (1 or 2) problems that share plan `pl` (and the template instance: ups, fp8)
+static int dispatch(const Plan& pl, int ups, bool w8, const KP2& kp, int count, hipStream_t stream) {
   const int tiles = pl.tiles_m * pl.tiles_n;
   int rc = 0;
-  if (p.wscale) {
+  if (w8) {
     switch (pl.tile) {
-      case 1: rc = launch_dma_w8<128, 64, 3>(kp, tiles, stream); break;
-      case 2: rc = launch_dma_w8<64, 64, 4>(kp, tiles, stream); break;
-      case 6: rc = launch_dma_w8<64, 160, 3>(kp, tiles, stream); break;
-      case 9: rc = launch_dma_w8<32, 160, 4>(kp, tiles, stream); break;
-      case 19: rc = launch_dma_w8<64, 64, 8>(kp, tiles, stream); break;
-      case 20: rc = launch_dma_w8<32, 160, 6>(kp, tiles, stream); break;
+      case 1: rc = launch_dma_w8<128, 64, 3>(kp, count, tiles, stream); break;
+      case 2: rc = launch_dma_w8<64, 64, 4>(kp, count, tiles, stream); break;
+      case 6: rc = launch_dma_w8<64, 160, 3>(kp, count, tiles, stream); break;
+      case 9: rc = launch_dma_w8<32, 160, 4>(kp, count, tiles, stream); break;
+      case 19: rc = launch_dma_w8<64, 64, 8>(kp, count, tiles, stream); break;
+      case 20: rc = launch_dma_w8<32, 160, 6>(kp, count, tiles, stream); break;
       default: return fail("conv_gemm: tile %d has no fp8-weight instantiation", pl.tile);
     }
   } else
   switch (pl.tile) {
-    case 0: rc = launch_dma<128, 128, 3>(p.ups, kp, tiles, stream); break;
-    case 1: rc = launch_dma<128, 64, 3>(p.ups, kp, tiles, stream); break;
-    case 2: rc = launch_dma<64, 64, 4>(p.ups, kp, tiles, stream); break;
-    case 3: { static bool d = false; rc = launch_k(&conv_gemm_kernel<128, 64, 32, true>, 2 * (128 + 64) * 64, &d, kp, tiles, stream); break; }
-    case 4: { static bool d = false; rc = launch_k(&conv_gemm_kernel<64, 64, 32, true>, 2 * (64 + 64) * 64, &d, kp, tiles, stream); break; }
-    case 5: rc = launch_dma<256, 128, 3>(p.ups, kp, tiles, stream); break;
-    case 6: rc = launch_dma<64, 160, 3>(p.ups, kp, tiles, stream); break;
-    case 7: rc = launch_dma<128, 160, 3>(p.ups, kp, tiles, stream); break;
-    case 8: rc = launch_dma<256, 160, 3>(p.ups, kp, tiles, stream); break;
-    case 9: rc = launch_dma<32, 160, 4>(p.ups, kp, tiles, stream); break;
-    case 10: rc = launch_dma<64, 160, 5>(p.ups, kp, tiles, stream); break;
-    case 11: rc = launch_dma<128, 160, 4>(p.ups, kp, tiles, stream); break;
-    case 12: rc = launch_dma<128, 64, 5>(p.ups, kp, tiles, stream); break;
-    case 19: rc = launch_dma<64, 64, 8>(p.ups, kp, tiles, stream); break;
-    case 20: rc = launch_dma<32, 160, 6>(p.ups, kp, tiles, stream); break;
-    case 21: rc = launch_dma<128, 128, 4>(p.ups, kp, tiles, stream); break;
+    case 0: rc = launch_dma<128, 128, 3>(ups, kp, count, tiles, stream); break;
+    case 1: rc = launch_dma<128, 64, 3>(ups, kp, count, tiles, stream); break;
+    case 2: rc = launch_dma<64, 64, 4>(ups, kp, count, tiles, stream); break;
+    case 3: { static bool d = false; rc = launch_k(&conv_gemm_kernel<128, 64, 32, true>, 2 * (128 + 64) * 64, &d, kp, count, tiles, stream); break; }
+    case 4: { static bool d = false; rc = launch_k(&conv_gemm_kernel<64, 64, 32, true>, 2 * (64 + 64) * 64, &d, kp, count, tiles, stream); break; }
+    case 5: rc = launch_dma<256, 128, 3>(ups, kp, count, tiles, stream); break;
+    case 6: rc = launch_dma<64, 160, 3>(ups, kp, count, tiles, stream); break;
+    case 7: rc = launch_dma<128, 160, 3>(ups, kp, count, tiles, stream); break;
+    case 8: rc = launch_dma<256, 160, 3>(ups, kp, count, tiles, stream); break;
+    case 9: rc = launch_dma<32, 160, 4>(ups, kp, count, tiles, stream); break;
+    case 10: rc = launch_dma<64, 160, 5>(ups, kp, count, tiles, stream); break;
+    case 11: rc = launch_dma<128, 160, 4>(ups, kp, count, tiles, stream); break;
+    case 12: rc = launch_dma<128, 64, 5>(ups, kp, count, tiles, stream); break;
+    case 19: rc = launch_dma<64, 64, 8>(ups, kp, count, tiles, stream); break;
+    case 20: rc = launch_dma<32, 160, 6>(ups, kp, count, tiles, stream); break;
+    case 21: rc = launch_dma<128, 128, 4>(ups, kp, count, tiles, stream); break;
     case 13: case 14: case 15: case 16: case 17: case 18: case 22: case 23: case 24: case 25:
-      SDEO_CHECK(halo_ok(p, kTiles[pl.tile]), "conv_gemm: halo plan on an ineligible problem");
-      rc = launch_halo(kTiles[pl.tile].stages, kp, pl.tiles_m, pl.tiles_n, stream);
+      rc = launch_halo(kTiles[pl.tile].stages, kp, count, pl.tiles_m, pl.tiles_n, stream);
       break;
     default: return fail("conv_gemm: bad tile %d", pl.tile);
   }
   if (rc) return rc;
   if (pl.splitk > 1) {
-    const int64_t n = (int64_t)p.M * (p.N / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, stream, kp);
+    const int64_t n = (int64_t)kp.k[0].M * (kp.k[0].N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n, 256), count), dim3(256), 0, stream, kp);
     SDEO_HIP(hipGetLastError());
   }
   return 0;
+}
+
+int conv_gemm(const ConvGemm& p, hipStream_t stream) {
+  Plan pl;
+  KP2 kk{};
+  if (int rc = prepare(p, pl, kk.k[0])) return rc;
+  return dispatch(pl, p.ups, p.wscale != nullptr, kk, 1, stream);
+}
+
+bool conv_gemm_can_pair(const ConvGemm& a, const ConvGemm& b) {
+  if (key_of(a) != key_of(b) || a.S != b.S || a.pad != b.pad || a.Ho != b.Ho || a.Wo != b.Wo) return false;
+  if (a.force_tile != b.force_tile || a.force_splitk != b.force_splitk) return false;
+  const Plan pa = make_plan(a), pb = make_plan(b);
+  return pa.tile == pb.tile && pa.splitk == pb.splitk && pa.nk == pb.nk && pa.tiles_m == pb.tiles_m && pa.tiles_n == pb.tiles_n;
+}
+
+int conv_gemm_pair(const ConvGemm& a, const ConvGemm& b, hipStream_t stream) {
+  if (!conv_gemm_can_pair(a, b)) {
+    if (int rc = conv_gemm(a, stream)) return rc;
+    return conv_gemm(b, stream);
+  }
+  Plan pl, pl2;
+  KP2 kk{};
+  if (int rc = prepare(a, pl, kk.k[0])) return rc;
+  if (int rc = prepare(b, pl2, kk.k[1])) return rc;
+  return dispatch(pl, a.ups, a.wscale != nullptr, kk, 2, stream);
 }
 
 int conv_gemm_read_stamps(unsigned long long* out, int n) {

@@ -29,7 +29,8 @@ constexpr int halo_stages(int ph, int pw, int bn) {
 // owning half as many pixels: an in-order wave alone on its SIMD exposes every fragment-read issue, wait and barrier between
 // its MFMA batches (measured 740 clocks per K-step for 320 clocks of MFMA); with a partner the SIMD interleaves the two.
 template <int PH, int PW, int BN, int NMW>
-__global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP p) {
+__global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP2 pp) {
+  const KP& p = pp.k[blockIdx.y];
   constexpr int BM = PH * PW;
   constexpr int MI = BM / (16 * NMW), NI = BN / 16;
   constexpr int HWD = PW + 2, XREAL = (PH + 2) * HWD;
@@ -281,7 +282,7 @@ const HaloCfg kHaloCfgs[] = {
 const int kNumHaloCfgs = 10;
 
 template <int PH, int PW, int BN, int NMW>
-static int launch_halo_t(const KP& kp, int tiles_m, int tiles_n, hipStream_t stream) {
+static int launch_halo_t(const KP2& kp, int count, int tiles_m, int tiles_n, hipStream_t stream) {
   constexpr int smem = 2 * halo_xbytes(PH, PW) + halo_stages(PH, PW, BN) * halo_wbytes(BN);
   static_assert(smem <= 160 * 1024, "LDS");
   static bool done = false;
@@ -290,24 +291,24 @@ static int launch_halo_t(const KP& kp, int tiles_m, int tiles_n, hipStream_t str
                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     done = true;
   }
-  hipLaunchKernelGGL((conv3x3_halo_kernel<PH, PW, BN, NMW>), dim3(tiles_m * tiles_n, 1, kp.splitk), dim3(NMW * 64 + 256), smem, stream,
+  hipLaunchKernelGGL((conv3x3_halo_kernel<PH, PW, BN, NMW>), dim3(tiles_m * tiles_n, count, kp.k[0].splitk), dim3(NMW * 64 + 256), smem, stream,
                      kp);
   SDEO_HIP(hipGetLastError());
   return 0;
 }
 
-int launch_halo(int variant, const KP& kp, int tiles_m, int tiles_n, hipStream_t stream) {
+int launch_halo(int variant, const KP2& kp, int count, int tiles_m, int tiles_n, hipStream_t stream) {
   switch (variant) {
-    case 0: return launch_halo_t<8, 16, 80, 4>(kp, tiles_m, tiles_n, stream);
-    case 1: return launch_halo_t<8, 16, 160, 4>(kp, tiles_m, tiles_n, stream);
-    case 2: return launch_halo_t<8, 8, 80, 4>(kp, tiles_m, tiles_n, stream);
-    case 3: return launch_halo_t<8, 8, 160, 4>(kp, tiles_m, tiles_n, stream);
-    case 4: return launch_halo_t<8, 16, 64, 4>(kp, tiles_m, tiles_n, stream);
-    case 5: return launch_halo_t<8, 16, 128, 4>(kp, tiles_m, tiles_n, stream);
-    case 6: return launch_halo_t<8, 16, 80, 8>(kp, tiles_m, tiles_n, stream);
-    case 7: return launch_halo_t<8, 16, 160, 8>(kp, tiles_m, tiles_n, stream);
-    case 8: return launch_halo_t<8, 16, 64, 8>(kp, tiles_m, tiles_n, stream);
-    case 9: return launch_halo_t<8, 16, 128, 8>(kp, tiles_m, tiles_n, stream);
+    case 0: return launch_halo_t<8, 16, 80, 4>(kp, count, tiles_m, tiles_n, stream);
+    case 1: return launch_halo_t<8, 16, 160, 4>(kp, count, tiles_m, tiles_n, stream);
+    case 2: return launch_halo_t<8, 8, 80, 4>(kp, count, tiles_m, tiles_n, stream);
+    case 3: return launch_halo_t<8, 8, 160, 4>(kp, count, tiles_m, tiles_n, stream);
+    case 4: return launch_halo_t<8, 16, 64, 4>(kp, count, tiles_m, tiles_n, stream);
+    case 5: return launch_halo_t<8, 16, 128, 4>(kp, count, tiles_m, tiles_n, stream);
+    case 6: return launch_halo_t<8, 16, 80, 8>(kp, count, tiles_m, tiles_n, stream);
+    case 7: return launch_halo_t<8, 16, 160, 8>(kp, count, tiles_m, tiles_n, stream);
+    case 8: return launch_halo_t<8, 16, 64, 8>(kp, count, tiles_m, tiles_n, stream);
+    case 9: return launch_halo_t<8, 16, 128, 8>(kp, count, tiles_m, tiles_n, stream);
     default: return fail("launch_halo: bad variant %d", variant);
   }
 }

@@ -46,6 +46,11 @@ struct KP {
   int stats_ld;
 };
 
+// What a kernel receives: one problem, or two independent problems of the SAME plan (grid, tile, split-K, template instance)
+// run by one launch, blockIdx.y selecting the problem ("pair launch": the ControlNet and the UNet encoder execute the same
+// sequence of shapes on different weights and activations, and at batch 1 a launch rarely fills the chip by itself).
+struct KP2 { KP k[2]; };
+
 // Ablation / stamp switches exist only in the measurement build: in the production library dbg_on() is the constant false and
 // every branch on it (and the stamp code) is compiled out of the K loops.
 #ifdef SDEO_DEBUG_KERNELS
@@ -393,6 +398,6 @@ __device__ __forceinline__ void wait_vmcnt() {
 struct HaloCfg { int ph, pw, bn; const char* name; };
 extern const HaloCfg kHaloCfgs[];
 extern const int kNumHaloCfgs;
-int launch_halo(int variant, const KP& kp, int tiles_m, int tiles_n, hipStream_t stream);
+int launch_halo(int variant, const KP2& kp, int count, int tiles_m, int tiles_n, hipStream_t stream);
 
 }  // namespace sdeo

@@ -48,6 +48,10 @@ struct ConvGemm {
   int stats_ld = 0;
 };
 int conv_gemm(const ConvGemm& p, hipStream_t stream);
+// Pair launch: two independent problems of one shape and plan in ONE launch (blockIdx.y selects the problem; a split-K plan
+// needs distinct workspaces).  Falls back to two launches when the plans differ.  Results are those of two single launches.
+bool conv_gemm_can_pair(const ConvGemm& a, const ConvGemm& b);
+int conv_gemm_pair(const ConvGemm& a, const ConvGemm& b, hipStream_t stream);
 // whether the plan chosen for p is a halo-reuse 3x3 kernel (which has no fp8-weight variant)
 bool conv_gemm_plan_is_halo(const ConvGemm& p);
 // strips (partials per row) a launch of p writes to stats_out; 0 when the chosen plan cannot emit them (split-K)
@@ -74,6 +78,17 @@ int gn_chunks(int HW);
 int groupnorm_nhwc(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const float* beta, int B, int HW, int C,
                    int groups, float eps, int with_silu, float* partials, hipStream_t stream);
 
+struct GnArgs {
+  f16* y; const f16* x; const float* gamma; const float* beta; float* partials;
+  int ldy, ldx, B, HW, C, groups;
+  float eps;
+  int with_silu;
+};
+int groupnorm_nhwc(const GnArgs& a, hipStream_t stream);
+// two GroupNorm problems of one shape in one launch (pair launch, see conv_gemm_pair); distinct `partials` required
+bool groupnorm_can_pair(const GnArgs& a, const GnArgs& b);
+int groupnorm_nhwc_pair(const GnArgs& a, const GnArgs& b, hipStream_t stream);
+
 // LayerNorm over the last dim of [rows][C] fp16 (two-pass in registers, fp32 math).
 int layernorm(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const float* beta, int rows, int C, float eps,
               hipStream_t stream);
@@ -86,6 +101,16 @@ int layernorm(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const 
 // ------------------------------------------------------------------------------------------
 int attention(f16* o, int ldo, const f16* q, int ldq, const f16* k, int ldk, const f16* v, int ldv, int B, int H,
               int Tq, int Tk, int TkS, int TkSv, int d, float scale, hipStream_t stream, int causal = 0);
+struct AttnArgs {
+  f16* o; const f16* q; const f16* k; const f16* v;
+  int ldo, ldq, ldk, ldv, B, H, Tq, Tk, TkS, TkSv, d;
+  float scale;
+  int causal;
+};
+int attention(const AttnArgs& a, hipStream_t stream);
+// two attention problems of one shape in one launch (pair launch, see conv_gemm_pair); falls back to two launches otherwise
+bool attention_can_pair(const AttnArgs& a, const AttnArgs& b);
+int attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t stream);
 // vt[c][b*TkSv + t] = v[(b*T + t)*ldv + c]   (VAE AttnBlock's materialised-score path)
 int transpose_pad(f16* vt, int ldvt, const f16* v, int ldv, int B, int T, int TkSv, int C, hipStream_t stream);
 

@@ -17,6 +17,11 @@ namespace sdeo {
 // statistics chunks per image: enough blocks to fill 256 CUs at the 64x64 level, capped so the
 // second-level sum stays short
 // upper bound of the statistics chunks per image (sizes the partial-sum workspace)
+// operands of one GroupNorm problem; a launch takes one or two problems of the same shape (pair launch, see KP2 in conv_inl.h):
+// batch entries >= Bper belong to the second
+struct GnOne { f16* y; const f16* x; const float* gamma; const float* beta; float* partials; int ldy, ldx; };
+struct GnPair { GnOne k[2]; };
+
 int gn_chunks(int HW) { const int c = cdiv(HW, 8); return c > 128 ? 128 : (c < 1 ? 1 : c); }
 
 // Channel vectors (8 x fp16 = 16 B) handled by one block: the largest divisor of C/8 that is <= 256 and
@@ -35,15 +40,18 @@ static int gn_vec_per_block(int C, int groups) {
 
 // grid: (chunks, channel-parts, B).  Thread (prow, cv) walks pixels prow, prow+P, ... of its chunk with a
 // fixed 8-channel vector cv, so a wave reads whole contiguous NHWC rows.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x, int ldx, int HW, int C, int cpg,
-                                                       int nvb, float* __restrict__ partials, int nchunks,
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnPair gp, int Bper, int HW, int C, int cpg, int nvb, int nchunks,
                                                        int groups, int ppc) {
+  const GnOne& g1 = gp.k[(int)blockIdx.z >= Bper];
+  const f16* __restrict__ x = g1.x;
+  const int ldx = g1.ldx;
+  float* __restrict__ partials = g1.partials;
   __shared__ float s_sum[256 * 8];
   __shared__ float s_sq[256 * 8];
   const int tid = threadIdx.x;
   const int P = 256 / nvb;
   const int cv = tid % nvb, prow = tid / nvb;
-  const int chunk = blockIdx.x, part = blockIdx.y, b = blockIdx.z;
+  const int chunk = blockIdx.x, part = blockIdx.y, b = (int)blockIdx.z >= Bper ? blockIdx.z - Bper : blockIdx.z;
   const int c0 = (part * nvb + cv) * 8;
   const int pbeg = chunk * ppc;
   const int pend = min(HW, pbeg + ppc);
@@ -121,10 +129,15 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x
 }
 
 // grid: (chunks, channel-parts, B): fold mean/rstd/gamma/beta into per-channel a,b in LDS, then y = x*a+b.
-__global__ __launch_bounds__(256) void gn_apply_kernel(f16* __restrict__ y, int ldy, const f16* __restrict__ x, int ldx,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       int HW, int C, int cpg, int nvb, const float* __restrict__ partials,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnPair gp, int Bper, int HW, int C, int cpg, int nvb,
                                                        int nchunks, int groups, float eps, int with_silu, int ppc, int nsc) {
+  const GnOne& g1 = gp.k[(int)blockIdx.z >= Bper];
+  f16* __restrict__ y = g1.y;
+  const f16* __restrict__ x = g1.x;
+  const int ldy = g1.ldy, ldx = g1.ldx;
+  const float* __restrict__ gamma = g1.gamma;
+  const float* __restrict__ beta = g1.beta;
+  const float* __restrict__ partials = g1.partials;
   __shared__ float s_a[256 * 8];
   __shared__ float s_b[256 * 8];
   __shared__ float s_mean[64];
@@ -132,7 +145,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(f16* __restrict__ y, int 
   const int tid = threadIdx.x;
   const int P = 256 / nvb;
   const int cv = tid % nvb, prow = tid / nvb;
-  const int chunk = blockIdx.x, part = blockIdx.y, b = blockIdx.z;
+  const int chunk = blockIdx.x, part = blockIdx.y, b = (int)blockIdx.z >= Bper ? blockIdx.z - Bper : blockIdx.z;
   const int gpb = nvb * 8 / cpg;
   const bool active = prow < P;
   const int c0 = (part * nvb + cv) * 8;
@@ -241,16 +254,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(f16* __restrict__ y, int 
 // normalises from LDS.  A vector of 8 channels spans at most two groups ("slots"), checked on the host.
 // ------------------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(NT) void gn_fused_kernel(f16* __restrict__ y, int ldy, const f16* __restrict__ x, int ldx,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int HW,
-                                                      int cpg, int nvw, int nsweep, float eps, int with_silu) {
+__global__ __launch_bounds__(NT) void gn_fused_kernel(const GnPair gp, int Bper, int HW, int cpg, int nvw, int nsweep, float eps,
+                                                      int with_silu) {
+  const GnOne& g1 = gp.k[(int)blockIdx.y >= Bper];
+  f16* __restrict__ y = g1.y;
+  const f16* __restrict__ x = g1.x;
+  const int ldy = g1.ldy, ldx = g1.ldx;
+  const float* __restrict__ gamma = g1.gamma;
+  const float* __restrict__ beta = g1.beta;
   extern __shared__ __attribute__((aligned(16))) char gsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int P = NT / nvw;                       // pixel rows per sweep
   const int v = tid % nvw, prow = tid / nvw;
   const bool active = prow < P;
-  const int part = blockIdx.x, b = blockIdx.y;
+  const int part = blockIdx.x, b = (int)blockIdx.y >= Bper ? blockIdx.y - Bper : blockIdx.y;
   const int c0 = (part * nvw + v) * 8;          // parts start on a group boundary
   char* slice = gsm;                                                                  // [nsweep][NT] 16-byte vectors
   float2* part_sq = reinterpret_cast<float2*>(gsm + (size_t)nsweep * NT * 16);        // [2 * nvw][P]
@@ -376,8 +394,7 @@ static size_t gn_fused_smem(int HW, int nvw) {
 }
 
 template <int NT>
-static int launch_gn_fused(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const float* beta, int B, int HW, int C,
-                           int cpg, int nvw, float eps, int with_silu, hipStream_t stream) {
+static int launch_gn_fused(const GnPair& gp, int count, int B, int HW, int C, int cpg, int nvw, float eps, int with_silu, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
     SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -385,18 +402,23 @@ static int launch_gn_fused(f16* y, int ldy, const f16* x, int ldx, const float* 
     attr_done = true;
   }
   const int P = NT / nvw, nsweep = cdiv(HW, P);
-  hipLaunchKernelGGL((gn_fused_kernel<NT>), dim3((C / 8) / nvw, B), dim3(NT), gn_fused_smem<NT>(HW, nvw), stream, y, ldy, x, ldx,
-                     gamma, beta, HW, cpg, nvw, nsweep, eps, with_silu);
+  hipLaunchKernelGGL((gn_fused_kernel<NT>), dim3((C / 8) / nvw, B * count), dim3(NT), gn_fused_smem<NT>(HW, nvw), stream, gp, B, HW,
+                     cpg, nvw, nsweep, eps, with_silu);
   SDEO_HIP(hipGetLastError());
   return 0;
 }
 
-int groupnorm_nhwc(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const float* beta, int B, int HW, int C,
-                   int groups, float eps, int with_silu, float* partials, hipStream_t stream) {
-  SDEO_CHECK(y && x && gamma && beta && partials, "groupnorm: null operand");
-  SDEO_CHECK(B > 0 && HW > 0 && C > 0, "groupnorm: empty tensor");
-  SDEO_CHECK(groups > 0 && groups <= 64 && C % groups == 0, "groupnorm: C=%d not divisible into %d groups", C, groups);
-  SDEO_CHECK(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "groupnorm: C=%d ldx=%d ldy=%d must be multiples of 8", C, ldx, ldy);
+static int gn_check(const GnArgs& a) {
+  SDEO_CHECK(a.y && a.x && a.gamma && a.beta && a.partials, "groupnorm: null operand");
+  SDEO_CHECK(a.B > 0 && a.HW > 0 && a.C > 0, "groupnorm: empty tensor");
+  SDEO_CHECK(a.groups > 0 && a.groups <= 64 && a.C % a.groups == 0, "groupnorm: C=%d not divisible into %d groups", a.C, a.groups);
+  SDEO_CHECK(a.C % 8 == 0 && a.ldx % 8 == 0 && a.ldy % 8 == 0, "groupnorm: C=%d ldx=%d ldy=%d must be multiples of 8", a.C, a.ldx, a.ldy);
+  return 0;
+}
+
+static int gn_dispatch(const GnArgs& a, const GnPair& gp, int count, hipStream_t stream) {
+  const int B = a.B, HW = a.HW, C = a.C, groups = a.groups, with_silu = a.with_silu;
+  const float eps = a.eps;
   const int cpg = C / groups;
   {
     static const int two_pass = [] { const char* e = getenv("SDEO_GN_TWO_PASS"); return e ? atoi(e) : 0; }();
@@ -409,9 +431,9 @@ int groupnorm_nhwc(f16* y, int ldy, const f16* x, int ldx, const float* gamma, c
       static const int max_hw = [] { const char* e = getenv("SDEO_GN_FUSED_MAX_HW"); return e ? atoi(e) : 256; }();
       if (HW <= max_hw) {
         if (cdiv(HW, 256 / nvw) <= 8 && gn_fused_smem<256>(HW, nvw) <= kGnFusedLdsCap)
-          return launch_gn_fused<256>(y, ldy, x, ldx, gamma, beta, B, HW, C, cpg, nvw, eps, with_silu, stream);
+          return launch_gn_fused<256>(gp, count, B, HW, C, cpg, nvw, eps, with_silu, stream);
         if (cdiv(HW, 1024 / nvw) <= 60 && gn_fused_smem<1024>(HW, nvw) <= kGnFusedLdsCap)
-          return launch_gn_fused<1024>(y, ldy, x, ldx, gamma, beta, B, HW, C, cpg, nvw, eps, with_silu, stream);
+          return launch_gn_fused<1024>(gp, count, B, HW, C, cpg, nvw, eps, with_silu, stream);
       }
     }
   }
@@ -425,16 +447,46 @@ int groupnorm_nhwc(f16* y, int ldy, const f16* x, int ldx, const float* gamma, c
   int chunks = cdiv(HW, 4 * P);
   if (chunks > 2048) chunks = 2048;
   const int ppc = cdiv(HW, chunks);
-  dim3 grid(chunks, parts, B);
+  dim3 grid(chunks, parts, B * count);
   int sc = cdiv(HW, 8 * P);
   { const int mxs = gn_chunks(HW) < 128 ? gn_chunks(HW) : 128; sc = sc < 1 ? 1 : (sc > mxs ? mxs : sc); }
   const int sppc = cdiv(HW, sc);
-  dim3 sgrid(sc, parts, B);
-  hipLaunchKernelGGL(gn_stats_kernel, sgrid, dim3(256), 0, stream, x, ldx, HW, C, cpg, nvb, partials, sc, groups, sppc);
-  hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, stream, y, ldy, x, ldx, gamma, beta, HW, C, cpg, nvb, partials,
-                     chunks, groups, eps, with_silu, ppc, sc);
+  dim3 sgrid(sc, parts, B * count);
+  hipLaunchKernelGGL(gn_stats_kernel, sgrid, dim3(256), 0, stream, gp, B, HW, C, cpg, nvb, sc, groups, sppc);
+  hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, stream, gp, B, HW, C, cpg, nvb, chunks, groups, eps, with_silu, ppc, sc);
   SDEO_HIP(hipGetLastError());
   return 0;
+}
+
+static GnOne gn_one(const GnArgs& a) { return GnOne{a.y, a.x, a.gamma, a.beta, a.partials, a.ldy, a.ldx}; }
+
+int groupnorm_nhwc(const GnArgs& a, hipStream_t stream) {
+  if (int rc = gn_check(a)) return rc;
+  GnPair gp{};
+  gp.k[0] = gp.k[1] = gn_one(a);
+  return gn_dispatch(a, gp, 1, stream);
+}
+
+bool groupnorm_can_pair(const GnArgs& a, const GnArgs& b) {
+  return a.B == b.B && a.HW == b.HW && a.C == b.C && a.groups == b.groups && a.eps == b.eps && a.with_silu == b.with_silu;
+}
+
+int groupnorm_nhwc_pair(const GnArgs& a, const GnArgs& b, hipStream_t stream) {
+  if (!groupnorm_can_pair(a, b) || a.partials == b.partials) {
+    if (int rc = groupnorm_nhwc(a, stream)) return rc;
+    return groupnorm_nhwc(b, stream);
+  }
+  if (int rc = gn_check(a)) return rc;
+  if (int rc = gn_check(b)) return rc;
+  GnPair gp{};
+  gp.k[0] = gn_one(a);
+  gp.k[1] = gn_one(b);
+  return gn_dispatch(a, gp, 2, stream);
+}
+
+int groupnorm_nhwc(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const float* beta, int B, int HW, int C,
+                   int groups, float eps, int with_silu, float* partials, hipStream_t stream) {
+  return groupnorm_nhwc(GnArgs{y, x, gamma, beta, partials, ldy, ldx, B, HW, C, groups, eps, with_silu}, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
