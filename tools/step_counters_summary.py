@@ -101,7 +101,7 @@ def main():
         print("summary skipped, missing", e)
     json.dump(out, open(out_path, "w"), indent=1)
     for name in out:
-        if name.startswith("_"):
+        if name.startswith("_") or name == "summary":
             continue
         for cn, v in out[name]["per_ddim_step"].items():
             print(f"{name:12s} {cn:28s} per DDIM step = {v['per_ddim_step']:.6g}")
