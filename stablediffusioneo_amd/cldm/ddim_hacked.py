@@ -65,7 +65,17 @@ class DDIMSampler(object):
         setattr(self, name, attr)
 
     def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
-        """`cldm/ddim_hacked.py:23-52`."""
+        """`cldm/ddim_hacked.py:23-52`.  The buffers depend only on (steps, discretisation, eta) and the model's schedule, so a repeat
+        call with the same arguments keeps them: the reference rebuilds them for every image, which here would cost a stream
+        synchronisation (the pageable host -> device copies below) and leave the GPU idle between two images."""
+        key = (int(ddim_num_steps), str(ddim_discretize), float(ddim_eta), id(self.model), self.ddpm_num_timesteps)
+        if getattr(self, "_schedule_key", None) == key:
+            return
+        self._schedule_key = None
+        self._make_schedule(ddim_num_steps, ddim_discretize, ddim_eta, verbose)
+        self._schedule_key = key
+
+    def _make_schedule(self, ddim_num_steps, ddim_discretize, ddim_eta, verbose):
         self.ddim_timesteps = make_ddim_timesteps(ddim_discr_method=ddim_discretize, num_ddim_timesteps=ddim_num_steps,
                                                   num_ddpm_timesteps=self.ddpm_num_timesteps, verbose=verbose)
         alphas_cumprod = self.model.alphas_cumprod

@@ -131,7 +131,7 @@ class SdeoRuntime:
     def configure(self, n: int, h: int, w: int):
         if (n, h, w) != (self.n, self.h, self.w):
             self._graph_key = None
-            self._graph = None
+            self._graphs = None
             self.generation += 1
             self.n = self.h = self.w = 0            # a failed configure leaves the handle unconfigured
             check(self.lib.sdeo_configure(self.handle, C.c_int(n), C.c_int(h), C.c_int(w)), "configure")
@@ -226,13 +226,15 @@ class SdeoRuntime:
             flags = HINT_CACHED | CONTEXT_CACHED
             self.apply_model(self._gx, None, self._gt, None, scales, only_mid_control, flags, self._geps)   # warm-up, eager
             torch.cuda.synchronize(self.device)
+            # (measured, tools/step_replay.py: two instances of the capture replayed alternately are SLOWER, 6.91 vs 6.78 ms per
+            # step; the host enqueues a replay in 1.6 ms, so the step is GPU-bound and one instance is enough)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.apply_model(self._gx, None, self._gt, None, scales, only_mid_control, flags, self._geps)
-            self._graph, self._graph_key = g, key
+            self._graphs, self._graph_key = [g], key
         self._gx.copy_(x)
         self._gt.copy_(t)
-        self._graph.replay()
+        self._graphs[0].replay()
         return self._geps
 
     def vae_decode(self, z, want_u8: bool = False):

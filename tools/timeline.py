@@ -10,8 +10,9 @@ from collections import defaultdict
 db = sys.argv[1]
 tail = int(sys.argv[2]) if len(sys.argv) > 2 else 9000
 c = sqlite3.connect(db)
-rows = c.execute("select start, end, queue_id, name from kernels where name like '%sdeo%' order by start").fetchall()
+rows = c.execute("select start, end, queue_id, name from kernels order by start").fetchall()     # every kernel, torch's own included
 rows = rows[-tail:]
+print(f"of which not libsdeo's: {sum(1 for r in rows if 'sdeo' not in r[3])} kernels, {sum(r[1] - r[0] for r in rows if 'sdeo' not in r[3]) / 1e6:.2f} ms")
 t0, t1 = rows[0][0], max(r[1] for r in rows)
 print(f"{len(rows)} kernels over {(t1 - t0) / 1e6:.2f} ms")
 byq = defaultdict(list)
@@ -47,3 +48,21 @@ for q, ks in byq.items():
             after[nm][0] += g; after[nm][1] += 1
 for nm, (g, n) in sorted(after.items(), key=lambda kv: -kv[1][0])[:12]:
     print(f"  gap after {nm:60s} n={n:5d} mean {g / n / 1e3:5.2f} us total {g / 1e6:6.2f} ms")
+
+# chip-wide idle intervals (no kernel of any queue running): which kernels stand on either side of the long ones
+def short(n):
+    return n.split("(")[0].replace("void ", "").replace("sdeo::", "")[:44]
+ends = sorted(rows, key=lambda r: r[0])
+idle = []
+cur_end, cur_name = ends[0][1], ends[0][3]
+for s_, e_, q_, n_ in ends[1:]:
+    if s_ > cur_end:
+        idle.append((s_ - cur_end, cur_name, n_))
+    if e_ > cur_end:
+        cur_end, cur_name = e_, n_
+agg = defaultdict(lambda: [0, 0])
+for g, a, b in idle:
+    agg[(short(a), short(b))][0] += g; agg[(short(a), short(b))][1] += 1
+print(f"chip-wide idle: {len(idle)} intervals, {sum(g for g, _, _ in idle) / 1e6:.2f} ms; by (kernel before -> kernel after):")
+for (a, b), (g, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:16]:
+    print(f"  {a:44s} -> {b:44s} n={n:5d} mean {g / n / 1e3:7.2f} us total {g / 1e6:6.2f} ms")
