@@ -221,6 +221,42 @@ def test_hint_and_context_are_computed_once_per_image(tiny_model):
     assert counts[2] - counts[1] == 2 * per_step, counts
 
 
+def test_whole_loop_graph_equals_per_step_replay(tiny_model):
+    """Steps 2..S replayed from ONE captured graph (ddim_hacked._loop_graphed) run the same launches in the same order as the
+    per-step path: final latent and every kept intermediate are bitwise equal, for `sample` and `sample_simple`, and the graph
+    captured for one image serves the next image's NEW hint / context (they live in the runtime's caches, not in the graph)."""
+    import stablediffusioneo_amd.cldm.ddim_hacked as dh
+    m = tiny_model
+    m.control_scales = [0.9 ** (12 - i) for i in range(13)]
+    dev = m.device
+    cd = m.rt.ucfg.context_dim
+    s = dh.DDIMSampler(m)
+    saved = dh.USE_LOOP_GRAPH
+    try:
+        for img_seed in (3, 11):                      # second image: other hint, other prompts, same graph
+            x, _, _ = make_inputs(1, 8, 16, ctx_dim=cd, x_seed=100 + img_seed)
+            hint = make_hint(1, 64, 128, seed=img_seed).to(dev)
+            cond = {"c_concat": [hint], "c_crossattn": [randn((1, 77, cd), img_seed).to(dev)]}
+            unc = {"c_concat": [hint], "c_crossattn": [randn((1, 77, cd), img_seed + 1).to(dev)]}
+            out = {}
+            for mode in (True, False):
+                dh.USE_LOOP_GRAPH = mode
+                z, inter = s.sample(6, 1, (4, 8, 16), cond, verbose=False, eta=0.0, unconditional_guidance_scale=7.5,
+                                    unconditional_conditioning=unc, x_T=x.to(dev), log_every_t=2)
+                z2, inter2 = s.sample_simple(6, 1, (4, 8, 16), cond, verbose=False, eta=0.0, unconditional_guidance_scale=7.5,
+                                             unconditional_conditioning=unc, x_T=x.to(dev), log_every_t=2)
+                out[mode] = (z.clone(), [t.clone() for t in inter["x_inter"]], [t.clone() for t in inter["pred_x0"]], z2.clone())
+            a, b = out[True], out[False]
+            assert torch.isfinite(a[0]).all() and float(a[0].abs().max()) > 0
+            assert torch.equal(a[0], b[0]) and torch.equal(a[3], b[3]) and torch.equal(a[0], a[3])
+            assert len(a[1]) == len(b[1]) == 5 and len(a[2]) == len(b[2])          # x_T, step 1, and indices 4, 2, 0
+            for u, v in zip(a[1] + a[2], b[1] + b[2]):
+                assert torch.equal(u, v)
+    finally:
+        dh.USE_LOOP_GRAPH = saved
+        m.control_scales = [1.0] * 13
+
+
 def test_ddim_encode_vs_oracle(tiny_model):
     """DDIMSampler.encode (DDIM inversion, `cldm/ddim_hacked.py:233-279`) against the oracle's restatement; tolerance as for
     sampling: a trajectory feeds fp16 network error back through the steps"""
