@@ -81,7 +81,9 @@ int sdeo_layernorm_f16(void* y, const void* x, const float* gamma, const float* 
 
 /* Fused attention O = softmax(Q K^T scale) V.  Q [b][tq][ldq], K [b][tk_stride][ldk], V [b][v_batch_stride][ldv] (all
  * row-major, head h at column h*d: column blocks of one fused q/k/v projection work as they are);  O [b][tq][ldo].
- * Keys >= tk are masked.  Operands 16-byte aligned, ld* multiples of 8. */
+ * Keys >= tk are masked.  Operands 16-byte aligned, ld* multiples of 8.  Head dim d: a multiple of 8 up to 160 (the UNet /
+ * ControlNet / CLIP heads), or 256 / 512 (the VAE AttnBlock's single head, `ldm/modules/diffusionmodules/model.py:179-203`:
+ * the four waves of a workgroup split the channels); scores are never materialised for any of them. */
 int sdeo_attention_f16(void* o, int ldo, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int b,
                        int heads, int tq, int tk, int tk_stride, int v_batch_stride, int d, float scale, void* stream);
 

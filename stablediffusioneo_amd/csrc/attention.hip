@@ -328,6 +328,198 @@ void attention_kernel(const AP2 pp) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide heads (d = 256 / 512: the VAE AttnBlock, `ldm/modules/diffusionmodules/model.py:179-203`, one head of 512 channels).
+// 32 queries x d fp32 of O do not fit one wave's registers, so the four waves of a workgroup share ONE block of 32 queries and
+// split the CHANNELS: wave w owns channels [w*DS, (w+1)*DS).  Per 32-key tile each wave forms the partial S^T = K[:, slice] Q[:, slice]^T
+// of its slice, the four partials are summed through LDS in a fixed order (identical full scores in every wave, deterministic),
+// every wave runs the same online softmax on them (redundant VALU work, but no second exchange), and multiplies P into ITS slice
+// of V: O^T[slice] += V[:, slice]^T P^T.  MFMA layouts, the in-register P^T operand and the transposing V reads are those of
+// attention_kernel above.  K / V tiles: 32 keys x d, register-staged, double-buffered in LDS.
+// ------------------------------------------------------------------------------------------------
+template <int DS>
+__global__ __launch_bounds__(256, 1) void attention_wide_kernel(const AP p) {
+  constexpr int D = 4 * DS;                                   // head dim
+  constexpr int KS16 = DS / 16;                               // QK^T k-steps per wave
+  constexpr int DT = DS / 32;                                 // 32-row tiles of O^T per wave
+  constexpr int KROW = D * 2 + 16;                            // K tile row bytes: odd multiple of 16
+  constexpr int VROW = D * 2 + 64;                            // V tile row bytes: 64 (mod 256), see attn_vrow
+  constexpr int KBYTES = 32 * KROW, VBYTES = 32 * VROW, STAGE = KBYTES + VBYTES;
+  constexpr int CH = D / 8;                                   // 16-byte chunks per row
+  constexpr int PASS = 32 * CH / 256;                         // chunks per thread per tile (K and V each)
+  static_assert(KROW % 32 == 16 && VROW % 256 == 64 && (32 * CH) % 256 == 0, "tile geometry");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xch = smem + 2 * STAGE;                               // partial-score exchange: [wave][lane][16] fp32 (16 KB)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane & 31, lh = lane >> 5;
+  const int qtiles = (p.Tq + 31) >> 5;
+  const int bh = blockIdx.x / qtiles;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int q0 = (blockIdx.x - bh * qtiles) * 32;
+  const int qrow = q0 + lq;
+  const bool qvalid = qrow < p.Tq;
+  const int c0 = wave * DS;                                   // first channel of this wave's slice
+
+  f16x8 qf[KS16];
+  {
+    const f16* qp = p.q + ((size_t)b * p.Tq + (qvalid ? qrow : 0)) * p.ldq + h * D + c0;
+#pragma unroll
+    for (int ks = 0; ks < KS16; ++ks)
+      qf[ks] = qvalid ? *reinterpret_cast<const f16x8*>(qp + (ks * 2 + lh) * 8) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+
+  const f16* kbase = p.k + (size_t)b * p.TkS * p.ldk + h * D;
+  const f16* vbase = p.v + (size_t)b * p.TkSv * p.ldv + h * D;
+  const int ntiles = (p.Tk + 31) / 32;
+  const f16x8 zero8 = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  f16x8 kr[PASS], vr[PASS];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < PASS; ++i) {
+      const int it = tid + i * 256;
+      const int row = it / CH, c = it - row * CH;
+      const int key = kt * 32 + row;
+      const bool ok = key < p.Tk;                            // rows >= Tk: K zero (masked anyway), V zero (P is 0 there)
+      kr[i] = ok ? *reinterpret_cast<const f16x8*>(kbase + (size_t)key * p.ldk + c * 8) : zero8;
+      vr[i] = ok ? *reinterpret_cast<const f16x8*>(vbase + (size_t)key * p.ldv + c * 8) : zero8;
+    }
+  };
+  auto store_tile = [&](int stage) {
+    char* ks_ = smem + stage * STAGE;
+    char* vs_ = ks_ + KBYTES;
+#pragma unroll
+    for (int i = 0; i < PASS; ++i) {
+      const int it = tid + i * 256;
+      const int row = it / CH, c = it - row * CH;
+      *reinterpret_cast<f16x8*>(ks_ + row * KROW + c * 16) = kr[i];
+      *reinterpret_cast<f16x8*>(vs_ + row * VROW + c * 16) = vr[i];
+    }
+  };
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < ntiles;
+    if (more) load_tile(kt + 1);
+    const char* ks_ = smem + cur * STAGE;
+    const char* vs_ = ks_ + KBYTES;
+
+    // ---- partial S^T over this wave's channel slice
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS16; ++ks) {
+      const f16x8 kf = *reinterpret_cast<const f16x8*>(ks_ + lq * KROW + (c0 / 8 + ks * 2 + lh) * 16);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+    }
+    {
+      f32x4* dst = reinterpret_cast<f32x4*>(xch + (wave * 64 + lane) * 64);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) dst[g] = f32x4{s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]};
+    }
+    __syncthreads();
+    // ---- full scores: the four partials in a fixed order (every wave computes the same bits)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(xch + (w * 64 + lane) * 64);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = src[g];
+        s[4 * g] += v[0]; s[4 * g + 1] += v[1]; s[4 * g + 2] += v[2]; s[4 * g + 3] += v[3];
+      }
+    }
+    // ---- online softmax (base 2); key of s[r] = kt*32 + (r&3) + 8*(r>>2) + 4*lh
+    const bool tail = (kt + 1) * 32 > p.Tk;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (tail && kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh >= p.Tk) s[r] = -INFINITY;
+      mx = fmaxf(mx, s[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * p.scale_log2);       // tile 0 always holds key 0: finite from the first tile on
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, -m_new));
+      s[r] = pv;
+      rs += pv;
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run = l_run * alpha + rs;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      m_run = m_new;
+    }
+    // ---- O^T[slice] += V[:, slice]^T P^T
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      f16x8 pf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = (f16)s[8 * st + j];
+      const char* vblk = vs_ + (16 * st + 4 * lh + ((lane & 15) >> 2)) * VROW + (c0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        typedef __attribute__((address_space(3))) h16x4* lds_h4;
+        const h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(vblk + t * 64));
+        const h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(vblk + t * 64 + 8 * VROW));
+        const f16x8 vf = __builtin_shufflevector(__builtin_bit_cast(f16x4, lo), __builtin_bit_cast(f16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
+      }
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();                                           // buffer swap; the exchange area is free again
+  }
+
+  if (qvalid) {
+    const float inv = 1.0f / l_run;
+    f16* op = p.o + ((size_t)b * p.Tq + qrow) * p.ldo + h * D + c0;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f16x4 ov;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ov[j] = (f16)(o[t][4 * g + j] * inv);
+        *reinterpret_cast<f16x4*>(op + t * 32 + 8 * g + 4 * lh) = ov;
+      }
+  }
+}
+
+template <int DS>
+static int launch_attn_wide(const AP& ap, int B, hipStream_t stream) {
+  constexpr int D = 4 * DS;
+  constexpr int smem = 2 * (32 * (D * 2 + 16) + 32 * (D * 2 + 64)) + 4 * 64 * 16 * 4;
+  static_assert(smem <= 160 * 1024, "LDS");
+  static bool attr_done = false;
+  if (!attr_done) {
+    SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_wide_kernel<DS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((attention_wide_kernel<DS>), dim3(cdiv(ap.Tq, 32) * B * ap.H), dim3(256), smem, stream, ap);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int D16, int KS>
 static int launch_attn_ks(const AP2& ap2, int count, int B, hipStream_t stream) {
   const AP& ap = ap2.k[0];
@@ -368,7 +560,9 @@ static int attn_prepare(AP& ap, const AttnArgs& a) {
   SDEO_CHECK(a.o && a.q && a.k && a.v, "attention: null operand");
   SDEO_CHECK(a.B > 0 && a.H > 0 && a.Tq > 0 && a.Tk > 0 && a.TkS >= a.Tk && a.TkSv >= a.Tk,
              "attention: bad sizes B=%d H=%d Tq=%d Tk=%d TkS=%d TkSv=%d", a.B, a.H, a.Tq, a.Tk, a.TkS, a.TkSv);
-  SDEO_CHECK(a.d % 8 == 0 && a.d >= 8 && a.d <= 160, "attention: head dim %d unsupported (multiple of 8, <= 160)", a.d);
+  SDEO_CHECK((a.d % 8 == 0 && a.d >= 8 && a.d <= 160) || a.d == 256 || a.d == 512,
+             "attention: head dim %d unsupported (multiple of 8 up to 160, or 256 / 512)", a.d);
+  SDEO_CHECK(a.d <= 160 || !a.causal, "attention: causal masking is not built for head dim %d", a.d);
   SDEO_CHECK(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 4 == 0,
              "attention: strides must keep 16-byte alignment (ldq=%d ldk=%d ldv=%d ldo=%d)", a.ldq, a.ldk, a.ldv, a.ldo);
   SDEO_CHECK((reinterpret_cast<uintptr_t>(a.q) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.k) & 15) == 0 &&
@@ -397,11 +591,13 @@ static int attn_dispatch(const AP2& ap, int count, int B, hipStream_t stream) {
 int attention(const AttnArgs& a, hipStream_t stream) {
   AP2 ap{};
   if (int rc = attn_prepare(ap.k[0], a)) return rc;
+  if (a.d == 512) return launch_attn_wide<128>(ap.k[0], a.B, stream);
+  if (a.d == 256) return launch_attn_wide<64>(ap.k[0], a.B, stream);
   return attn_dispatch(ap, 1, a.B, stream);
 }
 
 bool attention_can_pair(const AttnArgs& a, const AttnArgs& b) {
-  return a.B == b.B && a.H == b.H && a.Tq == b.Tq && a.Tk == b.Tk && a.d == b.d && a.causal == b.causal;
+  return a.d <= 160 && a.B == b.B && a.H == b.H && a.Tq == b.Tq && a.Tk == b.Tk && a.d == b.d && a.causal == b.causal;
 }
 
 int attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t stream) {

@@ -1162,29 +1162,42 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
     T y = vres(d + ".mid.block_1", hcur, bin, bin);
     b.release(hcur);
     hcur = y;
-    {   // AttnBlock (`model.py:179-203`): single head over h*w tokens, scores materialised in fp32
+    {   // AttnBlock (`model.py:179-203`): single head of `bin` channels over h*w tokens
       const std::string p = d + ".mid.attn_1";
       const int Tn = h * w;
       T g = b.gn(hcur, p + ".norm", 1e-6f, 0);
       T q = b.conv(g, p + ".q", bin, 1, 1, 0);
       T k = b.conv(g, p + ".k", bin, 1, 1, 0);
-      T vt = b.gemm_t(g, b.wptr(p + ".v.weight"), bin, bin, b.vptr(p + ".v.bias"));
-      b.release(g);
-      T s32 = b.alloc2d(Tn, Tn * 2);
-      float* sp = reinterpret_cast<float*>(s32.p);
-      b.gemm(q, k.p, k.ld, Tn, nullptr, Builder::CO(), sp, Tn);
-      b.release(q);
-      b.release(k);
-      T pr = b.alloc2d(Tn, Tn);
-      {
-        f16* pp = pr.p; const float sc = 1.0f / sqrtf((float)bin);
-        b.push([=](hipStream_t s) { return softmax_rows(pp, Tn, sp, Tn, Tn, Tn, sc, s); });
+      T o;
+      if ((bin % 8 == 0 && bin <= 160) || bin == 256 || bin == 512) {
+        // flash attention (d = 512 on the wide-head kernel: the four waves of a workgroup split the channels)
+        T v = b.conv(g, p + ".v", bin, 1, 1, 0);
+        b.release(g);
+        o = b.alloc(1, h, w, bin);
+        b.attn(o, q.p, q.ld, k.p, k.ld, v.p, v.ld, 1, 1, Tn, Tn, Tn, Tn, bin);
+        b.release(q);
+        b.release(k);
+        b.release(v);
+      } else {
+        // other widths: scores materialised in fp32, row softmax, second GEMM
+        T vt = b.gemm_t(g, b.wptr(p + ".v.weight"), bin, bin, b.vptr(p + ".v.bias"));
+        b.release(g);
+        T s32 = b.alloc2d(Tn, Tn * 2);
+        float* sp = reinterpret_cast<float*>(s32.p);
+        b.gemm(q, k.p, k.ld, Tn, nullptr, Builder::CO(), sp, Tn);
+        b.release(q);
+        b.release(k);
+        T pr = b.alloc2d(Tn, Tn);
+        {
+          f16* pp = pr.p; const float sc = 1.0f / sqrtf((float)bin);
+          b.push([=](hipStream_t s) { return softmax_rows(pp, Tn, sp, Tn, Tn, Tn, sc, s); });
+        }
+        b.release(s32);
+        o = b.gemm(pr, vt.p, vt.ld, bin, nullptr);
+        o.n = 1; o.h = h; o.w = w;
+        b.release(pr);
+        b.release(vt);
       }
-      b.release(s32);
-      T o = b.gemm(pr, vt.p, vt.ld, bin, nullptr);
-      o.n = 1; o.h = h; o.w = w;
-      b.release(pr);
-      b.release(vt);
       Builder::CO ro; ro.res = &hcur;
       T yo = b.conv(o, p + ".proj_out", bin, 1, 1, 0, ro);
       b.release(o);

@@ -355,8 +355,12 @@ ATTN_CASES = [  # (B, heads, Tq, Tk, d)
     # token counts of the benchmarked configurations: 64x64 latent (T = 4096, BASELINE configs[1]) and 96x96 (T = 9216 /
     # 2304, configs[3]); B = 1 and 2 heads keep the fp32 reference's score tensor small
     (1, 2, 4096, 4096, 40), (1, 2, 4096, 77, 40), (1, 2, 9216, 9216, 40), (1, 2, 2304, 2304, 80), (1, 2, 9216, 77, 40),
-    # ragged sizes on the long-sequence kernel (64 queries per wave, 128-key tiles): query / key tails inside a tile
+    # ragged long sequences: query / key tails inside a tile
     (2, 3, 2100, 2100, 40), (1, 2, 2049, 1100, 40), (1, 1, 2304, 1024, 40), (1, 2, 2500, 1281, 40),
+    # wide heads (attention_wide_kernel: four waves split the channels): the VAE AttnBlock is one head of 512 channels over
+    # T = 4096 (`model.py:179-203`); ragged query / key counts, two heads, d = 256
+    (1, 1, 4096, 4096, 512), (1, 1, 1024, 1024, 512), (2, 1, 100, 77, 512), (1, 2, 333, 130, 512), (1, 1, 64, 64, 512),
+    (1, 1, 1024, 1024, 256), (2, 2, 200, 45, 256),
 ]
 
 
