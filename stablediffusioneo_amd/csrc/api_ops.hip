@@ -32,6 +32,7 @@ extern "C" {
 const char* sdeo_last_error(void) { return g_last_error.c_str(); }
 int sdeo_version(void) { return 100; }
 void sdeo_debug_force_gemm_plan(int tile, int splitk) { conv_gemm_debug_force(tile, splitk); }
+void sdeo_debug_set_gemm_persist(int on) { conv_gemm_set_persist(on); }
 void sdeo_debug_force_gemm_order(int order) { conv_gemm_debug_force_order(order); }
 void sdeo_set_tuned_gemm_plan(const int* key10, int tile, int splitk) { conv_gemm_set_tuned(key10, tile, splitk); }
 const char* sdeo_tuned_gemm_plans_json(void) {

@@ -47,9 +47,16 @@ namespace sdeo {
 // a weight-tile row is 64 bytes per K-step instead of 128, one DMA pass of the 256 loading threads covers 64 rows, and the
 // MFMA waves widen each 8-byte fragment to fp16 in registers (v_cvt_scalef32_pk_f16_fp8, exact) right before its MFMAs.
 // The activations, the accumulation and the epilogue are those of the fp16 kernel; what changes is the bytes streamed.
-template <int BM, int BN, int STAGES, bool UPS, bool WS, bool W8 = false>
+// PERSIST (wave-specialised, unsplit plans with more tiles than resident workgroups): gridDim.x workgroups walk the tile list with
+// stride gridDim.x.  The loader waves never stop at a tile boundary: while the MFMA waves run the epilogue of tile t the ring already
+// receives the first PF K-steps of tile t + 1, so the DMA latency in front of a tile (~1.4 us) and the
+// epilogue overlap instead of adding up.  K-steps are numbered through all tiles of the workgroup (ring slot = step % STAGES, one
+// barrier per step on both sides as before) plus ONE barrier per tile in front of the epilogue, after which the slot of the tile's
+// last step -- the only one the loaders do not refill before the next tile's first barrier -- is the waves' epilogue scratch.
+template <int BM, int BN, int STAGES, bool UPS, bool WS, bool W8 = false, bool PERSIST = false>
 __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2 pp) {
   const KP& p = pp.k[blockIdx.y];
+  static_assert(!PERSIST || WS, "the persistent tile loop is built on the loader / MFMA role split");
   constexpr int BK = 64, RPP = 32;
   constexpr int WRPP = W8 ? 64 : 32;                           // weight rows per DMA pass
   constexpr int XP = BM / RPP, WP = (BN + WRPP - 1) / WRPP, L = XP + WP;     // DMA instructions per loading thread per stage
@@ -65,10 +72,14 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
   const bool do_mma = !WS || wave_all < 4;
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // indices inside the role
   const int wm = wave & 1, wn = wave >> 1;
-  const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-  const int tm = p.n_fastest ? tile / p.tiles_n : tile % p.tiles_m;
-  const int tn = p.n_fastest ? tile % p.tiles_n : tile / p.tiles_m;
-  const int m0 = tm * BM, n0 = tn * BN;
+  int m0, n0;
+  auto set_tile = [&](int t) {             // t: position in the (XCD-aware) tile order
+    const int tile = xcd_remap(t, p.tiles_m * p.tiles_n);
+    const int tm = p.n_fastest ? tile / p.tiles_n : tile % p.tiles_m;
+    const int tn = p.n_fastest ? tile % p.tiles_n : tile / p.tiles_m;
+    m0 = tm * BM; n0 = tn * BN;
+  };
+  set_tile(blockIdx.x);
   const int z = blockIdx.z;
   const int kbeg = z * p.nk_per_split;
   const int kend = min(p.nk, kbeg + p.nk_per_split);
@@ -90,8 +101,9 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
   const char* wptr[WP];
   int winc[WP];
   const int tapsteps = p.Cin >> 6;
-  int st_c = kbeg % tapsteps, st_r = (kbeg / tapsteps) / p.S, st_s = (kbeg / tapsteps) % p.S;   // next K-step to issue
-  if (do_load) {
+  int st_c, st_r, st_s;                                                                         // next K-step to issue
+  auto loader_setup = [&]() {              // gather state of tile (m0, n0)
+    st_c = kbeg % tapsteps; st_r = (kbeg / tapsteps) / p.S; st_s = (kbeg / tapsteps) % p.S;
     const int Hv = UPS ? 2 * p.Hi : p.Hi, Wv = UPS ? 2 * p.Wi : p.Wi;
     const int R = p.K / (p.S * p.Cin);
     const bool linear = !UPS && p.K == p.Cin && p.stride == 1 && p.pad == 0;   // Linear / conv1x1: row m IS pixel m
@@ -144,7 +156,8 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
         winc[i] = nv ? BK : 0;
       }
     }
-  }
+  };
+  if (do_load) loader_setup();
 
   // issue the DMAs of the NEXT K-step into ring slot `slot` (every loading lane issues exactly L of them)
   auto issue = [&](int slot) {
@@ -189,7 +202,38 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
     });
   };
 
-  if constexpr (WS) {
+  // persistent mode: this workgroup's tiles are blockIdx.x + j * gridDim.x; K-steps are numbered through all of them
+  const int my_tiles = PERSIST ? (p.tiles_m * p.tiles_n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 1;
+  if constexpr (PERSIST) {
+    if (!do_mma) {                         // ---- loader waves, all tiles
+      const int total = my_tiles * nk;
+      int gi = 0, gk = 0, tj = 0;          // next global step to issue, its K-step inside its tile, tiles set up so far
+      auto issue_next = [&]() {
+        if (gk == 0 && tj > 0) { set_tile(blockIdx.x + tj * gridDim.x); loader_setup(); }
+        if (gk == 0) ++tj;
+        issue(gi % STAGES);
+        ++gi;
+        if (++gk == nk) gk = 0;
+      };
+#pragma unroll
+      for (int s = 0; s < PF; ++s)
+        if (gi < total) issue_next();
+      int kk = 0;
+      for (int g = 0; g < total; ++g) {
+        const int ahead = min(PF - 1, total - 1 - g);
+        static_for<PF>([&](auto A) {
+          if (ahead == A.value) wait_vmcnt<A.value * L>();
+        });
+        __builtin_amdgcn_s_barrier();
+        if (gi < total) issue_next();
+        if (++kk == nk) {
+          kk = 0;
+          __builtin_amdgcn_s_barrier();      // the MFMA waves' pre-epilogue barrier of this tile
+        }
+      }
+      return;
+    }
+  } else if constexpr (WS) {
     if (!do_mma) {                         // ---- loader waves
       if (nk > 0) {
 #pragma unroll
@@ -206,17 +250,21 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
     }
   }
 
+  const int frow = lane & 15, fq = lane >> 4;
+  for (int tj = 0; tj < my_tiles; ++tj) {        // one pass unless PERSIST
+  if (PERSIST && tj > 0) set_tile(blockIdx.x + tj * gridDim.x);
+  const int g0 = PERSIST ? tj * nk : 0;          // global number of this tile's first K-step
   f32x4 acc[NI][MI];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int frow = lane & 15, fq = lane >> 4;
 
   // LayerNorm folded into this GEMM: (rstd, rstd * mean) of the tile's rows from the producer's per-strip partials, summed by
   // the MFMA waves of column 0 while the first K-step is in flight (they would wait on the first barrier otherwise) and parked
   // in LDS behind the ring; the epilogue reads two floats per row instead of re-summing up to N/32 partials per lane.
-  float2* lnsm = reinterpret_cast<float2*>(smem + STAGES * STAGE);
+  // (PERSIST: two copies by tile parity -- a wave may write the next tile's scalars while another still reads this tile's)
+  float2* lnsm = reinterpret_cast<float2*>(smem + STAGES * STAGE) + (PERSIST ? (tj & 1) * BM : 0);
   const bool ln_lds = p.ln_stats != nullptr && p.splitk == 1;
   if (ln_lds && wn == 0) {
     for (int rr = lane; rr < TM; rr += 64) {
@@ -288,7 +336,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
   };
   auto compute = [&](int it) {
     if constexpr (DB) {
-      const unsigned sb = (it % STAGES) * STAGE;
+      const unsigned sb = ((g0 + it) % STAGES) * STAGE;
       wfrag wf0[NI], wf1[NI];
       f16x8 xf0[MI], xf1[MI];
       static_for<NI>([&](auto I) { lds_read_w<I.value * WSTEP>(wf0[I.value], wa0 + sb); });
@@ -304,7 +352,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
       mma_half(wf1, xf1);
       __builtin_amdgcn_sched_barrier(0);
     } else {
-      const char* xs = smem + (it % STAGES) * STAGE;
+      const char* xs = smem + ((g0 + it) % STAGES) * STAGE;
       const char* wsm = xs + XBYTES;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -344,11 +392,11 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
         stamp(p, 1);
         __builtin_amdgcn_s_barrier();        // step 0 visible
         stamp(p, 2);
-        reads0(0);
-        reads1(0);
+        reads0((g0 % STAGES) * STAGE);
+        reads1((g0 % STAGES) * STAGE);
         for (int it = 0; it < nk; ++it) {
           const bool more = it + 1 < nk;
-          const unsigned sbn = ((it + 1) % STAGES) * STAGE;
+          const unsigned sbn = ((g0 + it + 1) % STAGES) * STAGE;
           asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NI + MI) : "memory");
           __builtin_amdgcn_sched_barrier(0);
           if (!dbg_on(p, 4)) mma_half(wf0, xf0);
@@ -387,14 +435,16 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
   __builtin_amdgcn_s_barrier();
   stamp(p, 3);
   if (dbg_on(p, 32)) return;
-  static_assert(4 * epilogue_scratch_bytes(TN) <= STAGES * STAGE, "epilogue scratch");
-  epilogue<NI, MI, TM, TN>(p, acc, m0, n0, wm, wn, frow, fq, z, bpre, use_bpre, smem + wave * epilogue_scratch_bytes(TN),
-                           ln_lds ? lnsm + wm * TM : nullptr);
+  static_assert(4 * epilogue_scratch_bytes(TN) <= (PERSIST ? 1 : STAGES) * STAGE, "epilogue scratch");
+  // PERSIST: the scratch is the slot of the tile's LAST K-step (the other slots already receive the next tile)
+  char* scratch = smem + (PERSIST ? ((g0 + nk - 1) % STAGES) * STAGE : 0) + wave * epilogue_scratch_bytes(TN);
+  epilogue<NI, MI, TM, TN>(p, acc, m0, n0, wm, wn, frow, fq, z, bpre, use_bpre, scratch, ln_lds ? lnsm + wm * TM : nullptr);
   if (dbg_on(p, 64)) {
     stamp(p, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(p, 5);
   }
+  }   // tile loop
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -651,8 +701,16 @@ static const TileCfg kTiles[] = {
     {128, 160, 64, 7, TK_HALO, 1.0f, 1, "conv3x3_halo_kernel<8,16,160,8>"},
     {128, 64, 64, 8, TK_HALO, 1.0f, 1, "conv3x3_halo_kernel<8,16,64,8>"},
     {128, 128, 64, 9, TK_HALO, 1.0f, 1, "conv3x3_halo_kernel<8,16,128,8>"},
+    // many-tile, short-K problems (ff.net.0.proj, q|k|v: thousands of tiles of 5 - 10 K-steps): a tile's prologue, K loop and
+    // epilogue are each ~2 us and serial inside a workgroup (tools/stamps.py), so what overlaps them is OTHER workgroups on the
+    // same CU.  Four-wave workgroups (no loader waves: half the register footprint per workgroup) on a two-slot ring fit three
+    // or four to a CU.
+    {128, 64, 64, 2, TK_DMA, 0.85f, 3, "conv_gemm_dma_kernel<128,64,2>"},
+    {64, 64, 64, 2, TK_DMA, 0.65f, 4, "conv_gemm_dma_kernel<64,64,2>"},
+    {128, 128, 64, 2, TK_DMA, 1.00f, 2, "conv_gemm_dma_kernel<128,128,2>"},
 };
-static const int kNumTiles = 26;
+static const int kNumTiles = 29;
+static bool tile_is_light(int t) { return t >= 26 && t <= 28; }     // four-wave (non-specialised) instantiations
 static const int kNumCU = 256;
 
 struct Plan { int tile; int splitk; int nk; int tiles_m, tiles_n; };
@@ -712,6 +770,7 @@ static Plan make_plan(const ConvGemm& p) {
     };
     if (!usable(t)) continue;
     if (c.kind == TK_HALO && force_tile != t) continue;      // halo tiles enter through the measured plan table or a forced plan only
+    if (tile_is_light(t) && force_tile != t) continue;       // so do the four-wave tiles
     if (force_tile >= 0 && usable(force_tile) && force_tile != t) continue;
     const int tmn = plan_tiles_m(p, c), tnn = cdiv(p.N, c.bn);
     const int tiles = tmn * tnn;
@@ -790,13 +849,59 @@ static int launch_dma_w8(const KP2& kp, int count, int tiles, hipStream_t stream
   return launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, true, true>, smem, &done, kp, count, tiles, stream, 512);
 }
 
+// persistent tile loop (see conv_gemm_dma_kernel).  OFF by default: measured on MI355X (tools/gemm_tiles.py, tools/gpu_session_q.sh)
+// it is worth 5 % on the ff.net.0.proj GEMMs and nothing on the step (7.05 vs 7.03 ms) -- these launches are bound by L2 -> LDS
+// operand traffic (~9 TB/s chip-wide), not by the per-tile prologue it hides.  SDEO_GEMM_PERSIST=1 or
+// conv_gemm_set_persist(1) turns it on (tests, A/B).
+static int g_persist = -1;
+void conv_gemm_set_persist(int on) { g_persist = on ? 1 : 0; }
+static bool use_persist() {
+#ifdef SDEO_DEBUG_KERNELS
+  return false;
+#else
+  if (g_persist < 0) { const char* e = getenv("SDEO_GEMM_PERSIST"); g_persist = e ? (atoi(e) != 0) : 0; }
+  return g_persist != 0;
+#endif
+}
+
+template <typename K>
+static int launch_persist(K kernel, int smem, bool* attr_done, const KP2& kp, int count, int wgs, hipStream_t stream) {
+  if (!*attr_done) {
+    SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    *attr_done = true;
+  }
+  hipLaunchKernelGGL(kernel, dim3(wgs, count, 1), dim3(512), smem, stream, kp);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int BM, int BN, int ST>
 static int launch_dma(int ups, const KP2& kp, int count, int tiles, hipStream_t stream) {
-  static bool done[4] = {false, false, false, false};
+  static bool done[6] = {false, false, false, false, false, false};
   constexpr int smem = ST * (BM + BN) * 128 + BM * 8;      // ring + the LayerNorm row scalars (conv_gemm_dma_kernel: lnsm)
-  if (use_ws())
+  if (use_ws()) {
+    // more tiles than resident workgroups and an unsplit plan: the workgroups walk the tile list (loaders prefetch across tiles)
+    constexpr bool can_persist = 4 * epilogue_scratch_bytes(BN / 2) <= (BM + BN) * 128;
+    if constexpr (can_persist) {
+      constexpr int psmem = smem + BM * 8;
+      constexpr int occ = (160 * 1024) / psmem >= 2 ? 2 : 1;
+      const int wgs = kNumCU * occ;
+      if (use_persist() && kp.k[0].splitk == 1 && tiles > wgs)
+        return ups ? launch_persist(&conv_gemm_dma_kernel<BM, BN, ST, true, true, false, true>, psmem, &done[5], kp, count, wgs, stream)
+                   : launch_persist(&conv_gemm_dma_kernel<BM, BN, ST, false, true, false, true>, psmem, &done[4], kp, count, wgs, stream);
+    }
     return ups ? launch_k(&conv_gemm_dma_kernel<BM, BN, ST, true, true>, smem, &done[3], kp, count, tiles, stream, 512)
                : launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, true>, smem, &done[2], kp, count, tiles, stream, 512);
+  }
+  return ups ? launch_k(&conv_gemm_dma_kernel<BM, BN, ST, true, false>, smem, &done[1], kp, count, tiles, stream)
+             : launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, false>, smem, &done[0], kp, count, tiles, stream);
+}
+
+// four-wave workgroups on a two-slot ring (tiles 26..28)
+template <int BM, int BN, int ST>
+static int launch_dma_light(int ups, const KP2& kp, int count, int tiles, hipStream_t stream) {
+  static bool done[2] = {false, false};
+  constexpr int smem = ST * (BM + BN) * 128 + BM * 8;
   return ups ? launch_k(&conv_gemm_dma_kernel<BM, BN, ST, true, false>, smem, &done[1], kp, count, tiles, stream)
              : launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, false>, smem, &done[0], kp, count, tiles, stream);
 }
@@ -911,6 +1016,9 @@ static int dispatch(const Plan& pl, int ups, bool w8, const KP2& kp, int count, 
     case 19: rc = launch_dma<64, 64, 8>(ups, kp, count, tiles, stream); break;
     case 20: rc = launch_dma<32, 160, 6>(ups, kp, count, tiles, stream); break;
     case 21: rc = launch_dma<128, 128, 4>(ups, kp, count, tiles, stream); break;
+    case 26: rc = launch_dma_light<128, 64, 2>(ups, kp, count, tiles, stream); break;
+    case 27: rc = launch_dma_light<64, 64, 2>(ups, kp, count, tiles, stream); break;
+    case 28: rc = launch_dma_light<128, 128, 2>(ups, kp, count, tiles, stream); break;
     case 13: case 14: case 15: case 16: case 17: case 18: case 22: case 23: case 24: case 25:
       rc = launch_halo(kTiles[pl.tile].stages, kp, count, pl.tiles_m, pl.tiles_n, stream);
       break;
@@ -998,7 +1106,7 @@ int conv_gemm_autotune(const ConvGemm& p, hipStream_t stream) {
   if (!is_fast(p) || g_force_tile >= 0 || g_force_splitk > 0) return 0;
   const ShapeKey key = key_of(p);
   if (g_tuned.count(key)) return 0;
-  static const int tiles[] = {0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25};
+  static const int tiles[] = {0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28};
   static const int sks[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20};
   hipEvent_t a, b;
   SDEO_HIP(hipEventCreate(&a));

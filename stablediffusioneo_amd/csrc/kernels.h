@@ -63,6 +63,7 @@ size_t conv_gemm_workspace_bytes(const ConvGemm& p);
 // name of the kernel instantiation the launcher will pick (for profiles; matches the rocprof kernel name's template args)
 const char* conv_gemm_kernel_name(const ConvGemm& p);
 void conv_gemm_debug_force(int tile, int splitk);
+void conv_gemm_set_persist(int on);                // persistent tile loop of the wave-specialised kernel (off by default)
 void conv_gemm_debug_force_order(int order);       // -1 heuristic, 0 M-fastest, 1 N-fastest tile order
 // one-time on-device plan search for p's shape (p needs valid scratch pointers); workspace to reserve for it
 int conv_gemm_autotune(const ConvGemm& p, hipStream_t stream);

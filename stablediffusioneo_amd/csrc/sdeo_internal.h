@@ -11,6 +11,9 @@ extern "C" {
 
 /* force tile config / split-K of the following conv/GEMM launches (-1, 0 = plan table / heuristic) */
 void sdeo_debug_force_gemm_plan(int tile, int splitk);
+/* persistent tile loop of the wave-specialised implicit-GEMM kernel (unsplit plans with more tiles than resident workgroups);
+ * off by default (measured neutral on the step), same results either way */
+void sdeo_debug_set_gemm_persist(int on);
 void sdeo_debug_force_gemm_order(int order); /* -1 heuristic, 0 M-fastest, 1 N-fastest tile order within an XCD */
 /* name of the kernel instantiation sdeo_conv2d_nhwc_f16 would launch for this problem (plan table / forced plan / heuristic) */
 const char* sdeo_debug_conv2d_kernel_name(int n, int h, int w, int cin, int cout, int ksize, int stride, int upsample2x);

@@ -139,7 +139,7 @@ def test_conv2d_epilogue(ops):
     assert_close(y.permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3, what="conv epilogue")
 
 
-DMA_TILES = [0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 19, 20, 21]     # kTiles indices of conv_gemm_dma_kernel<BM,BN,STAGES> in csrc/conv_gemm.hip
+DMA_TILES = [0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 19, 20, 21, 26, 27, 28]     # kTiles indices of conv_gemm_dma_kernel<BM,BN,STAGES> in csrc/conv_gemm.hip
 
 
 @pytest.mark.parametrize("tile", DMA_TILES)
@@ -162,6 +162,38 @@ def test_conv2d_every_dma_tile(ops, tile, sk):
             assert_close(y.permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3, what=f"tile {tile} sk {sk} conv {(n, cin, h, w, cout, ups)}")
     finally:
         lib.sdeo_debug_force_gemm_plan(C.c_int(-1), C.c_int(0))
+
+
+PERSIST_TILES = [0, 1, 2, 6, 7, 10, 11, 12, 19, 21]     # tiles whose epilogue scratch fits one ring slot (BM <= 128): persistent tile loop
+
+
+@pytest.mark.parametrize("tile", PERSIST_TILES)
+def test_conv2d_persistent_tile_loop(ops, tile):
+    """More tiles than resident workgroups on an unsplit plan: the workgroups walk the tile list while the loader waves prefetch
+    across tile boundaries (conv_gemm_dma_kernel<..., PERSIST>).  Ragged M and N (the last tiles are partial), a 1x1 with a
+    residual, a 3x3, the folded upsample; every case has > 2 x 256 tiles for every tile shape in the list."""
+    import ctypes as C
+    from stablediffusioneo_amd import _lib
+    lib = _lib.load()
+    try:
+        lib.sdeo_debug_set_gemm_persist(C.c_int(1))            # off by default (measured neutral on the DDIM step)
+        lib.sdeo_debug_force_gemm_plan(C.c_int(tile), C.c_int(1))
+        for (n, cin, h, w, cout, k, ups) in [(1, 64, 125, 131, 328, 1, 0), (2, 64, 96, 100, 200, 3, 0), (1, 64, 70, 66, 264, 3, 1)]:
+            x = h16(randn((n, cin, h, w), 240 + cin))
+            wt = h16(randn((cout, cin, k, k), 241) * (1.0 / (cin * k * k)) ** 0.5)
+            bias = 0.1 * randn((cout,), 242)
+            xin = F.interpolate(x.float(), scale_factor=2, mode="nearest") if ups else x.float()
+            ref = F.conv2d(xin, wt.float(), bias, padding=k // 2)
+            res = None
+            if k == 1:
+                res = h16(randn(tuple(ref.shape), 243))
+                ref = ref + res.float()
+            y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), wt.permute(0, 2, 3, 1).contiguous().to(DEV), bias.to(DEV),
+                                res=None if res is None else res.permute(0, 2, 3, 1).contiguous().to(DEV), upsample2x=bool(ups))
+            assert_close(y.permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3, what=f"persistent tile {tile} conv {(n, cin, h, w, cout, k, ups)}")
+    finally:
+        lib.sdeo_debug_force_gemm_plan(C.c_int(-1), C.c_int(0))
+        lib.sdeo_debug_set_gemm_persist(C.c_int(0))
 
 
 HALO_TILES = {13: (8, 16, 80, 4), 14: (8, 16, 160, 4), 15: (8, 8, 80, 4), 16: (8, 8, 160, 4), 17: (8, 16, 64, 4), 18: (8, 16, 128, 4),

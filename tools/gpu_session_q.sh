@@ -1,11 +1,11 @@
 #!/bin/bash
-# quick check after a host-side change: sampler / engine / golden tests, then bench A/B of an env switch on the same box
+# quick check after a change: network / sampler / golden tests, then bench A/B of an env switch on the same box
 # usage: gpu_session_q.sh [VAR "v1 v2"]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r2q
 mkdir -p $OUT
 cd $R
-timeout -k 10 900 python -m pytest tests/test_sampler_gpu.py tests/test_fullsize_golden_gpu.py tests/test_engine_gpu.py -x -q -m gpu > $OUT/pytest.log 2>&1; rc=$?
+timeout -k 10 900 python -m pytest tests/test_sampler_gpu.py tests/test_fullsize_golden_gpu.py tests/test_nets_gpu.py tests/test_pair_gpu.py tests/test_fp8_gpu.py -x -q -m gpu > $OUT/pytest.log 2>&1; rc=$?
 tail -3 $OUT/pytest.log
 [ $rc -ne 0 ] && { grep -n "Error\|assert" $OUT/pytest.log | head -20; exit $rc; }
 VAR=${1:-SDEO_NONE}; VALS=${2:-x}
