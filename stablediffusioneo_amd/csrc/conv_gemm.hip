@@ -708,9 +708,14 @@ static const TileCfg kTiles[] = {
     {128, 64, 64, 2, TK_DMA, 0.85f, 3, "conv_gemm_dma_kernel<128,64,2>"},
     {64, 64, 64, 2, TK_DMA, 0.65f, 4, "conv_gemm_dma_kernel<64,64,2>"},
     {128, 128, 64, 2, TK_DMA, 1.00f, 2, "conv_gemm_dma_kernel<128,128,2>"},
+    {128, 160, 64, 2, TK_DMA, 1.10f, 2, "conv_gemm_dma_kernel<128,160,2>"},
+    {64, 160, 64, 2, TK_DMA, 0.90f, 2, "conv_gemm_dma_kernel<64,160,2>"},
+    {32, 160, 64, 2, TK_DMA, 0.60f, 3, "conv_gemm_dma_kernel<32,160,2>"},
+    {64, 64, 64, 3, TK_DMA, 0.65f, 3, "conv_gemm_dma_kernel<64,64,3>"},
+    {128, 64, 64, 3, TK_DMA, 0.85f, 2, "conv_gemm_dma_kernel<128,64,3>/4w"},
 };
-static const int kNumTiles = 29;
-static bool tile_is_light(int t) { return t >= 26 && t <= 28; }     // four-wave (non-specialised) instantiations
+static const int kNumTiles = 34;
+static bool tile_is_light(int t) { return t >= 26 && t <= 33; }     // four-wave (non-specialised) instantiations
 static const int kNumCU = 256;
 
 struct Plan { int tile; int splitk; int nk; int tiles_m, tiles_n; };
@@ -1019,6 +1024,11 @@ static int dispatch(const Plan& pl, int ups, bool w8, const KP2& kp, int count, 
     case 26: rc = launch_dma_light<128, 64, 2>(ups, kp, count, tiles, stream); break;
     case 27: rc = launch_dma_light<64, 64, 2>(ups, kp, count, tiles, stream); break;
     case 28: rc = launch_dma_light<128, 128, 2>(ups, kp, count, tiles, stream); break;
+    case 29: rc = launch_dma_light<128, 160, 2>(ups, kp, count, tiles, stream); break;
+    case 30: rc = launch_dma_light<64, 160, 2>(ups, kp, count, tiles, stream); break;
+    case 31: rc = launch_dma_light<32, 160, 2>(ups, kp, count, tiles, stream); break;
+    case 32: rc = launch_dma_light<64, 64, 3>(ups, kp, count, tiles, stream); break;
+    case 33: rc = launch_dma_light<128, 64, 3>(ups, kp, count, tiles, stream); break;
     case 13: case 14: case 15: case 16: case 17: case 18: case 22: case 23: case 24: case 25:
       rc = launch_halo(kTiles[pl.tile].stages, kp, count, pl.tiles_m, pl.tiles_n, stream);
       break;
@@ -1106,7 +1116,7 @@ int conv_gemm_autotune(const ConvGemm& p, hipStream_t stream) {
   if (!is_fast(p) || g_force_tile >= 0 || g_force_splitk > 0) return 0;
   const ShapeKey key = key_of(p);
   if (g_tuned.count(key)) return 0;
-  static const int tiles[] = {0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28};
+  static const int tiles[] = {0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33};
   static const int sks[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20};
   hipEvent_t a, b;
   SDEO_HIP(hipEventCreate(&a));

@@ -139,7 +139,7 @@ def test_conv2d_epilogue(ops):
     assert_close(y.permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3, what="conv epilogue")
 
 
-DMA_TILES = [0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 19, 20, 21, 26, 27, 28]     # kTiles indices of conv_gemm_dma_kernel<BM,BN,STAGES> in csrc/conv_gemm.hip
+DMA_TILES = [0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 19, 20, 21, 26, 27, 28, 29, 30, 31, 32, 33]     # kTiles indices of conv_gemm_dma_kernel<BM,BN,STAGES> in csrc/conv_gemm.hip
 
 
 @pytest.mark.parametrize("tile", DMA_TILES)

@@ -10,7 +10,7 @@ x = torch.randn(m, k, device="cuda").half()
 w = (torch.randn(n, k, device="cuda") * k ** -0.5).half()
 bias = torch.randn(n, device="cuda")
 names = {0: "128x128x3", 1: "128x64x3", 2: "64x64x4", 5: "256x128x3", 6: "64x160x3", 7: "128x160x3", 8: "256x160x3", 9: "32x160x4", 10: "64x160x5",
-         11: "128x160x4", 12: "128x64x5", 19: "64x64x8", 20: "32x160x6", 21: "128x128x4", 26: "128x64x2 L", 27: "64x64x2 L", 28: "128x128x2 L"}
+         11: "128x160x4", 12: "128x64x5", 19: "64x64x8", 20: "32x160x6", 21: "128x128x4", 26: "128x64x2 L", 27: "64x64x2 L", 28: "128x128x2 L", 29: "128x160x2 L", 30: "64x160x2 L", 31: "32x160x2 L", 32: "64x64x3 L", 33: "128x64x3 L"}
 def t(fn, reps=20):
     for _ in range(2): fn()
     torch.cuda.synchronize()
@@ -22,7 +22,7 @@ def t(fn, reps=20):
     a.record(); g.replay(); g.replay(); b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / (2 * reps) * 1e3
 for tile, nm in names.items():
-    if geglu and tile not in (0, 1, 2, 5, 12, 19, 21, 26, 27, 28): continue
+    if geglu and tile not in (0, 1, 2, 5, 12, 19, 21, 26, 27, 28, 32, 33): continue
     lib.sdeo_debug_force_gemm_plan(C.c_int(tile), C.c_int(1))
     try:
         if geglu:

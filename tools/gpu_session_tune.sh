@@ -1,10 +1,15 @@
 #!/bin/bash
-# tune the plans of shapes missing from the committed table (tools/tune_plans.py), install the merged table, then tests + bench
+# (re-)measure GEMM plans (tools/tune_plans.py; SDEO_TUNED_PLANS=0 in the environment = every shape, not just the missing ones),
+# install the table, then the op-level tile tests and two bench lines
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r2tune
 mkdir -p $OUT
 cd $R
-timeout -k 10 1000 python tools/tune_plans.py > $OUT/tune.log 2>&1; rc=$?; tail -3 $OUT/tune.log; echo "tune rc=$rc"
+timeout -k 10 1050 python tools/tune_plans.py > $OUT/tune.log 2>&1; rc=$?; tail -3 $OUT/tune.log; echo "tune rc=$rc"
 [ $rc -ne 0 ] && exit $rc
 cp $R/gpurun_out/tuned_plans_gfx950.json $R/stablediffusioneo_amd/tuned_plans_gfx950.json && cp $R/gpurun_out/tuned_plans_gfx950.json $OUT/
-bash tools/gpu_session_q.sh SDEO_NONE "x"
+for i in 1 2; do
+  timeout -k 10 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --fast-weights > $OUT/b.json 2> $OUT/b.err
+  python -c "
+import json; b=json.load(open('$OUT/b.json')); print(b['value'], 'img/s', b['ms_per_unet_step'], 'ms/step', b['ms_per_step'], 'ms/image')"
+done

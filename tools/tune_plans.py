@@ -14,6 +14,13 @@ from stablediffusioneo_amd import _lib, spec as S                 # noqa: E402
 from stablediffusioneo_amd.runtime import SdeoRuntime             # noqa: E402
 
 os.environ.setdefault("SDEO_AUTOTUNE", "1")      # measure every untabled shape on this device
+import threading, time                                            # noqa: E402
+_t0 = time.time()
+def _beat():                                                      # a configure can measure for minutes without printing
+    while True:
+        time.sleep(60)
+        print(f"... tuning, {time.time() - _t0:.0f} s", flush=True)
+threading.Thread(target=_beat, daemon=True).start()
 lib = _lib.load()
 start = len(_lib.dump_tuned_plans(lib))
 rt = SdeoRuntime(S.UNET_SD15, S.VAE_SD15)
