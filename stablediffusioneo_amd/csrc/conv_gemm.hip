@@ -437,8 +437,10 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
   if (dbg_on(p, 32)) return;
   static_assert(4 * epilogue_scratch_bytes(TN) <= (PERSIST ? 1 : STAGES) * STAGE, "epilogue scratch");
   // PERSIST: the scratch is the slot of the tile's LAST K-step (the other slots already receive the next tile)
-  char* scratch = smem + (PERSIST ? ((g0 + nk - 1) % STAGES) * STAGE : 0) + wave * epilogue_scratch_bytes(TN);
-  epilogue<NI, MI, TM, TN>(p, acc, m0, n0, wm, wn, frow, fq, z, bpre, use_bpre, scratch, ln_lds ? lnsm + wm * TM : nullptr);
+  constexpr int SCR = ((PERSIST ? 1 : STAGES) * STAGE / 4) & ~15;        // LDS each wave may use as epilogue scratch
+  constexpr int NBLK = epilogue_blocks(TN, MI, SCR);
+  char* scratch = smem + (PERSIST ? ((g0 + nk - 1) % STAGES) * STAGE : 0) + wave * SCR;
+  epilogue<NI, MI, TM, TN, NBLK>(p, acc, m0, n0, wm, wn, frow, fq, z, bpre, use_bpre, scratch, ln_lds ? lnsm + wm * TM : nullptr);
   if (dbg_on(p, 64)) {
     stamp(p, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -976,7 +978,7 @@ static int prepare(const ConvGemm& p, Plan& pl, KP& kp) {
 #endif
     kp.n_fastest = g_force_order >= 0 ? g_force_order : (cost_n_fast < cost_m_fast ? 1 : 0);
     static const int epi = [] { const char* e = getenv("SDEO_EPI_COALESCE"); return e ? atoi(e) : 1; }();
-    kp.coalesce = epi && p.y && !p.y32 && pl.splitk == 1 && p.act != 3 && !p.bias_per_row && p.N % 8 == 0 && p.ldy % 8 == 0 &&
+    kp.coalesce = epi && p.y && !p.y32 && pl.splitk == 1 && !p.bias_per_row && p.N % (p.act == 3 ? 16 : 8) == 0 && p.ldy % 8 == 0 &&
                   (reinterpret_cast<uintptr_t>(p.y) & 15) == 0 &&
                   (!p.res || (p.ldres % 8 == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0));
   }

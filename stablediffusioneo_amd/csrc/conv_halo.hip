@@ -246,7 +246,9 @@ __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP2 
   stamp_cycles(p, 15);
   if (dbg_on(p, 32)) return;
   static_assert(NMW * epilogue_scratch_bytes(BN) <= 2 * XBYTES + WST * WBYTES, "epilogue scratch");
-  epilogue_rows<NI, MI, BN>(p, acc, mrow, n0, fq, z, bpre, use_bpre, smem + wave * epilogue_scratch_bytes(BN));
+  constexpr int SCR = ((2 * XBYTES + WST * WBYTES) / NMW) & ~15;           // LDS each MFMA wave may use as epilogue scratch
+  constexpr int NBLK = epilogue_blocks(BN, MI, SCR);
+  epilogue_rows<NI, MI, BN, NBLK>(p, acc, mrow, n0, fq, z, bpre, use_bpre, smem + wave * SCR);
   if (dbg_on(p, 64)) {
     stamp(p, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

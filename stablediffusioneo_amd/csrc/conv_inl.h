@@ -96,6 +96,16 @@ __device__ __forceinline__ int swz_chunk(int row, int chunk) {
 // runs (measured: the 8-byte epilogue took ~4 us of a 24 us conv).  Same arithmetic, same single rounding.
 constexpr int epilogue_scratch_bytes(int tn) { return 16 * (tn * 4 + 16) + 16 * tn; }   // + [16 rows][tn / 8] float2 row-statistics partials
 
+// blocks staged per round: the largest divisor of MI whose scratch fits `budget` bytes per wave and whose residual registers
+// (PASSES 16-byte vectors per block) stay within 8 vectors
+constexpr int epilogue_blocks(int tn, int mi, int budget) {
+  const int passes = (16 * (tn / 8) + 63) / 64;
+  int best = 1;
+  for (int nb = 1; nb <= mi; ++nb)
+    if (mi % nb == 0 && nb * epilogue_scratch_bytes(tn) <= budget && nb * passes <= 8) best = nb;
+  return best;
+}
+
 // one 16-row block of the coalesced epilogue, flags resolved at compile time (a scalar branch per flag per tile cost more
 // than the arithmetic: ~60 taken branches per wave)
 template <int NI, int TN, bool B2, int ACT>
@@ -167,10 +177,15 @@ __device__ __forceinline__ void ln_correct(const KP& p, f32x4 (&acc)[NI][MI], co
   }
 }
 
-template <int NI, int MI, int TN>
+// NB = 16-row blocks staged per LDS round trip (scratch >= NB * epilogue_scratch_bytes(TN) per wave).  With NB = 1 a wave tile of
+// MI blocks costs MI dependent write -> read -> store chains; staging several blocks first issues their residual loads, LDS
+// reads and global stores back to back (measured with tools/gemm_ablate.py: the epilogue is ~40 % of a many-tile short-K GEMM
+// and of the order of a third of every ~8 us conv / GEMM launch).
+template <int NI, int MI, int TN, int NB = 1>
 __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI], const int (&mrow)[MI], int nb, int fq, int z,
                                               const f32x4 (&bpre)[NI], bool use_bpre, char* scratch = nullptr,
                                               const float2* lnrow = nullptr) {
+  static_assert(NB >= 1 && MI % NB == 0, "blocks per staging round");
   if (p.wscale && p.splitk == 1) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -181,10 +196,64 @@ __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI],
     }
   }
   if (p.ln_stats && p.splitk == 1) ln_correct<NI, MI>(p, acc, mrow, nb, fq, lnrow);
-  if (scratch && p.coalesce) {
+  if constexpr (NI % 2 == 0 && TN % 32 == 0) {
+    if (scratch && p.coalesce && p.act == 3) {
+      // GEGLU pair epilogue (see below) through the same LDS transposition: value * gelu(gate) is formed in the accumulator
+      // layout, staged as fp32 [16 rows][TN / 2] and stored in 16-byte pieces, TN bytes contiguous per row
+      constexpr int TNO = TN / 2, ROWB = TNO * 4 + 16, G = TNO / 8, PASSES = (16 * G + 63) / 64;
+      constexpr int BLOCKB = epilogue_scratch_bytes(TN);
+      const int lane = threadIdx.x & 63, frow = lane & 15;
+      f32x4 bias[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int n = nb + i * 16 + fq * 4;
+        bias[i] = use_bpre ? bpre[i] : ((p.bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f});
+      }
+      const int nbo = nb >> 1, No = p.N >> 1;
+#pragma unroll
+      for (int j0 = 0; j0 < MI; j0 += NB) {
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+          char* sc = scratch + jb * BLOCKB;
+#pragma unroll
+          for (int i = 0; i < NI; i += 2) {
+            const f32x4 v = acc[i][j0 + jb] + bias[i], g = acc[i + 1][j0 + jb] + bias[i + 1];
+            f32x4 o;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t] = v[t] * gelu_erf_f(g[t]);
+            *reinterpret_cast<f32x4*>(sc + frow * ROWB + ((i >> 1) * 16 + fq * 4) * 4) = o;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+          const char* sc = scratch + jb * BLOCKB;
+          const int m = mrow[j0 + jb];
+#pragma unroll
+          for (int t = 0; t < PASSES; ++t) {
+            const int id = t * 64 + lane;
+            const int r = id / G, n = nbo + (id - r * G) * 8;
+            const int msrc = __shfl(m, r & 15, 64);
+            if (id < 16 * G && n < No && msrc >= 0) {
+              const char* src = sc + r * ROWB + (n - nbo) * 4;
+              const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 16);
+              f16x8 o;
+#pragma unroll
+              for (int u = 0; u < 4; ++u) { o[u] = (f16)lo[u]; o[4 + u] = (f16)hi[u]; }
+              *reinterpret_cast<f16x8*>(p.y + (size_t)msrc * p.ldy + n) = o;
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      return;
+    }
+  }
+  if (scratch && p.coalesce && p.act != 3) {
     constexpr int ROWB = TN * 4 + 16;            // odd multiple of 16 bytes: the 16 rows of a block start in different banks
     constexpr int G = TN / 8;                    // 8-channel groups per row
     constexpr int PASSES = (16 * G + 63) / 64;
+    constexpr int BLOCKB = epilogue_scratch_bytes(TN);
     const int lane = threadIdx.x & 63, frow = lane & 15;
     // per-channel bias of this lane's tiles (zeros when absent), second-phase coordinates: the same for every block
     f32x4 bias[NI];
@@ -204,66 +273,85 @@ __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI],
     }
     const int mode = (p.bias2 ? 3 : 0) + p.act;   // act is 0..2 here (3 = GEGLU never takes this path)
 #pragma unroll
-    for (int j = 0; j < MI; ++j) {
-      const int m = mrow[j];
-      // residual loads of this block first: they are independent of the staging
-      int mm[PASSES];
-      f16x8 resv[PASSES];
+    for (int j0 = 0; j0 < MI; j0 += NB) {
+      // residual loads of these blocks first: they are independent of the staging
+      int mm[NB][PASSES];
+      f16x8 resv[NB][PASSES];
 #pragma unroll
-      for (int t = 0; t < PASSES; ++t) {
-        const int msrc = __shfl(m, rr[t] & 15, 64);          // lane r (fq == 0) holds the row index of block row r
-        mm[t] = live[t] ? msrc : -1;
-        resv[t] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      for (int jb = 0; jb < NB; ++jb) {
+        const int m = mrow[j0 + jb];
+#pragma unroll
+        for (int t = 0; t < PASSES; ++t) {
+          const int msrc = __shfl(m, rr[t] & 15, 64);          // lane r (fq == 0) holds the row index of block row r
+          mm[jb][t] = live[t] ? msrc : -1;
+          resv[jb][t] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
       }
       if (p.res) {
 #pragma unroll
-        for (int t = 0; t < PASSES; ++t)
-          if (mm[t] >= 0) resv[t] = *reinterpret_cast<const f16x8*>(p.res + (size_t)mm[t] * p.ldres + nn[t]);
-      }
-      f32x4 accj[NI];
+        for (int jb = 0; jb < NB; ++jb)
 #pragma unroll
-      for (int i = 0; i < NI; ++i) accj[i] = acc[i][j];
-      switch (mode) {
-        case 0: stage_block<NI, TN, false, 0>(p, accj, bias, m, nb, fq, frow, scratch); break;
-        case 1: stage_block<NI, TN, false, 1>(p, accj, bias, m, nb, fq, frow, scratch); break;
-        case 2: stage_block<NI, TN, false, 2>(p, accj, bias, m, nb, fq, frow, scratch); break;
-        case 3: stage_block<NI, TN, true, 0>(p, accj, bias, m, nb, fq, frow, scratch); break;
-        case 4: stage_block<NI, TN, true, 1>(p, accj, bias, m, nb, fq, frow, scratch); break;
-        default: stage_block<NI, TN, true, 2>(p, accj, bias, m, nb, fq, frow, scratch); break;
+          for (int t = 0; t < PASSES; ++t)
+            if (mm[jb][t] >= 0) resv[jb][t] = *reinterpret_cast<const f16x8*>(p.res + (size_t)mm[jb][t] * p.ldres + nn[t]);
+      }
+#pragma unroll
+      for (int jb = 0; jb < NB; ++jb) {
+        const int m = mrow[j0 + jb];
+        char* sc = scratch + jb * BLOCKB;
+        f32x4 accj[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) accj[i] = acc[i][j0 + jb];
+        switch (mode) {
+          case 0: stage_block<NI, TN, false, 0>(p, accj, bias, m, nb, fq, frow, sc); break;
+          case 1: stage_block<NI, TN, false, 1>(p, accj, bias, m, nb, fq, frow, sc); break;
+          case 2: stage_block<NI, TN, false, 2>(p, accj, bias, m, nb, fq, frow, sc); break;
+          case 3: stage_block<NI, TN, true, 0>(p, accj, bias, m, nb, fq, frow, sc); break;
+          case 4: stage_block<NI, TN, true, 1>(p, accj, bias, m, nb, fq, frow, sc); break;
+          default: stage_block<NI, TN, true, 2>(p, accj, bias, m, nb, fq, frow, sc); break;
+        }
       }
       __builtin_amdgcn_wave_barrier();
-      float2* spart = reinterpret_cast<float2*>(scratch + 16 * ROWB);     // [16 rows][G] partial (sum, sumsq) of the stored values
 #pragma unroll
-      for (int t = 0; t < PASSES; ++t) {
-        float ssum = 0.f, ssq = 0.f;
-        if (mm[t] >= 0) {
-          const char* src = scratch + rr[t] * ROWB + (nn[t] - nb) * 4;
-          const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 16);
-          f16x8 o;
+      for (int jb = 0; jb < NB; ++jb) {
+        const char* sc = scratch + jb * BLOCKB;
+        float2* spart = reinterpret_cast<float2*>(scratch + jb * BLOCKB + 16 * ROWB);     // [16 rows][G] partial (sum, sumsq) of the stored values
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            o[u] = (f16)(lo[u] + (float)resv[t][u]);
-            o[4 + u] = (f16)(hi[u] + (float)resv[t][4 + u]);
+        for (int t = 0; t < PASSES; ++t) {
+          float ssum = 0.f, ssq = 0.f;
+          if (mm[jb][t] >= 0) {
+            const char* src = sc + rr[t] * ROWB + (nn[t] - nb) * 4;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 16);
+            f16x8 o;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              o[u] = (f16)(lo[u] + (float)resv[jb][t][u]);
+              o[4 + u] = (f16)(hi[u] + (float)resv[jb][t][4 + u]);
+            }
+            *reinterpret_cast<f16x8*>(p.y + (size_t)mm[jb][t] * p.ldy + nn[t]) = o;
+            if (p.stats_out) {
+#pragma unroll
+              for (int u = 0; u < 8; ++u) { const float f = (float)o[u]; ssum += f; ssq += f * f; }
+            }
           }
-          *reinterpret_cast<f16x8*>(p.y + (size_t)mm[t] * p.ldy + nn[t]) = o;
-          if (p.stats_out) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const float f = (float)o[u]; ssum += f; ssq += f * f; }
-          }
+          if (p.stats_out && t * 64 + lane < 16 * G) spart[t * 64 + lane] = make_float2(ssum, ssq);     // index = row * G + group
         }
-        if (p.stats_out && t * 64 + lane < 16 * G) spart[t * 64 + lane] = make_float2(ssum, ssq);     // index = row * G + group
       }
       if (p.stats_out) {
         __builtin_amdgcn_wave_barrier();
-        if (lane < 16 && m >= 0 && nb < p.N) {   // lanes 0..15 have fq == 0 and frow == lane: `m` is the row index of block row `lane`;
-                                                 // a strip wholly past N (tile padding) has no slot in the statistics row
-          float ts = 0.f, tq = 0.f;
 #pragma unroll
-          for (int g = 0; g < G; ++g) { const float2 v = spart[lane * G + g]; ts += v.x; tq += v.y; }
-          reinterpret_cast<float2*>(p.stats_out)[(size_t)m * p.stats_ld + nb / TN] = make_float2(ts, tq);
+        for (int jb = 0; jb < NB; ++jb) {
+          const int m = mrow[j0 + jb];
+          const float2* spart = reinterpret_cast<const float2*>(scratch + jb * BLOCKB + 16 * ROWB);
+          if (lane < 16 && m >= 0 && nb < p.N) {   // lanes 0..15 have fq == 0 and frow == lane: `m` is the row index of block row `lane`;
+                                                   // a strip wholly past N (tile padding) has no slot in the statistics row
+            float ts = 0.f, tq = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) { const float2 v = spart[lane * G + g]; ts += v.x; tq += v.y; }
+            reinterpret_cast<float2*>(p.stats_out)[(size_t)m * p.stats_ld + nb / TN] = make_float2(ts, tq);
+          }
         }
       }
-      __builtin_amdgcn_wave_barrier();        // the next block overwrites the scratch rows
+      __builtin_amdgcn_wave_barrier();        // the next round overwrites the scratch rows
     }
     return;
   }
@@ -346,7 +434,7 @@ __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI],
 }
 
 // implicit-GEMM tiles: accumulator tile (i, j) of wave (wm, wn) is output row m0 + wm*TM + j*16 + frow
-template <int NI, int MI, int TM, int TN>
+template <int NI, int MI, int TM, int TN, int NB = 1>
 __device__ __forceinline__ void epilogue(const KP& p, f32x4 (&acc)[NI][MI], int m0, int n0, int wm, int wn, int frow, int fq, int z,
                                          const f32x4 (&bpre)[NI], bool use_bpre, char* scratch = nullptr,
                                          const float2* lnrow = nullptr) {
@@ -356,7 +444,7 @@ __device__ __forceinline__ void epilogue(const KP& p, f32x4 (&acc)[NI][MI], int 
     const int m = m0 + wm * TM + j * 16 + frow;
     mrow[j] = m < p.M ? m : -1;
   }
-  epilogue_rows<NI, MI, TN>(p, acc, mrow, n0 + wn * TN, fq, z, bpre, use_bpre, scratch, lnrow);
+  epilogue_rows<NI, MI, TN, NB>(p, acc, mrow, n0 + wn * TN, fq, z, bpre, use_bpre, scratch, lnrow);
 }
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (observed, speed only), so give each
