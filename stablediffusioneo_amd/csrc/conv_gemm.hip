@@ -432,6 +432,8 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
   }
   // every wave is done reading fragments and no DMA is pending (the last K-step was retired with vmcnt(0)): the ring becomes
   // the waves' private epilogue scratch
+  KP pe = p;                               // the epilogue's scalars in one batch of loads, in flight across the barrier
+  pin_epilogue_scalars(pe);
   __builtin_amdgcn_s_barrier();
   stamp(p, 3);
   if (dbg_on(p, 32)) return;
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
   constexpr int SCR = ((PERSIST ? 1 : STAGES) * STAGE / 4) & ~15;        // LDS each wave may use as epilogue scratch
   constexpr int NBLK = epilogue_blocks(TN, MI, SCR);
   char* scratch = smem + (PERSIST ? ((g0 + nk - 1) % STAGES) * STAGE : 0) + wave * SCR;
-  epilogue<NI, MI, TM, TN, NBLK>(p, acc, m0, n0, wm, wn, frow, fq, z, bpre, use_bpre, scratch, ln_lds ? lnsm + wm * TM : nullptr);
+  epilogue<NI, MI, TM, TN, NBLK>(pe, acc, m0, n0, wm, wn, frow, fq, z, bpre, use_bpre, scratch, ln_lds ? lnsm + wm * TM : nullptr);
   if (dbg_on(p, 64)) {
     stamp(p, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -241,6 +241,8 @@ __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP2 
     }
   }
   // all fragment reads done, no DMA pending: the patch / ring LDS becomes the waves' private epilogue scratch
+  KP pe = p;                               // the epilogue's scalars in one batch of loads, in flight across the barrier (conv_inl.h)
+  pin_epilogue_scalars(pe);
   __builtin_amdgcn_s_barrier();
   stamp(p, 3);
   stamp_cycles(p, 15);
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP2 
   static_assert(NMW * epilogue_scratch_bytes(BN) <= 2 * XBYTES + WST * WBYTES, "epilogue scratch");
   constexpr int SCR = ((2 * XBYTES + WST * WBYTES) / NMW) & ~15;           // LDS each MFMA wave may use as epilogue scratch
   constexpr int NBLK = epilogue_blocks(BN, MI, SCR);
-  epilogue_rows<NI, MI, BN, NBLK>(p, acc, mrow, n0, fq, z, bpre, use_bpre, smem + wave * SCR);
+  epilogue_rows<NI, MI, BN, NBLK>(pe, acc, mrow, n0, fq, z, bpre, use_bpre, smem + wave * SCR);
   if (dbg_on(p, 64)) {
     stamp(p, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -96,6 +96,36 @@ __device__ __forceinline__ int swz_chunk(int row, int chunk) {
 // runs (measured: the 8-byte epilogue took ~4 us of a 24 us conv).  Same arithmetic, same single rounding.
 constexpr int epilogue_scratch_bytes(int tn) { return 16 * (tn * 4 + 16) + 16 * tn; }   // + [16 rows][tn / 8] float2 row-statistics partials
 
+// The epilogue reads ~25 scalar parameters.  Left to the compiler they are loaded from the kernel-argument segment where first
+// used, one s_load + s_waitcnt lgkmcnt(0) after the other (the loads are invariant, so it prefers re-loading to keeping SGPRs
+// live across the K loop): a serial chain of scalar-cache round trips at the start of every epilogue.  Kernels therefore copy the
+// parameters right BEFORE the pre-epilogue barrier and pin the epilogue's fields in SGPRs here: one batch of wide loads whose
+// latency hides behind the barrier.
+__device__ __forceinline__ unsigned long long pin_u64(unsigned long long v) {
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ int pin_i32(int v) {
+  int r = __builtin_amdgcn_readfirstlane(v);
+  asm volatile("" : "+s"(r));
+  return r;
+}
+__device__ __forceinline__ float pin_f32(float v) { return __builtin_bit_cast(float, pin_i32(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ void pin_epilogue_scalars(KP& q) {
+  // pointers travel through the asm as integers and come back as GLOBAL pointers: pinned as generic pointers they would lose
+  // their address space and every access would become a flat_ one (which also counts on lgkmcnt and would serialise with the
+  // epilogue's LDS traffic)
+#define SDEO_PIN_PTR(f) q.f = (decltype(q.f))(__attribute__((address_space(1))) std::remove_pointer_t<decltype(q.f)>*)pin_u64((unsigned long long)q.f);
+  SDEO_PIN_PTR(y) SDEO_PIN_PTR(y32) SDEO_PIN_PTR(bias) SDEO_PIN_PTR(bias2) SDEO_PIN_PTR(res) SDEO_PIN_PTR(ws)
+  SDEO_PIN_PTR(wscale) SDEO_PIN_PTR(stats_out) SDEO_PIN_PTR(ln_stats) SDEO_PIN_PTR(ln_s)
+#undef SDEO_PIN_PTR
+  q.M = pin_i32(q.M); q.N = pin_i32(q.N); q.HoWo = pin_i32(q.HoWo); q.ldy = pin_i32(q.ldy); q.ldres = pin_i32(q.ldres);
+  q.ld_bias2 = pin_i32(q.ld_bias2); q.act = pin_i32(q.act); q.bias_per_row = pin_i32(q.bias_per_row); q.scale = pin_f32(q.scale);
+  q.splitk = pin_i32(q.splitk); q.coalesce = pin_i32(q.coalesce); q.stats_ld = pin_i32(q.stats_ld); q.ln_strips = pin_i32(q.ln_strips);
+  q.ln_ld = pin_i32(q.ln_ld); q.ln_invc = pin_f32(q.ln_invc); q.ln_eps = pin_f32(q.ln_eps);
+}
+
 // blocks staged per round: the largest divisor of MI whose scratch fits `budget` bytes per wave and whose residual registers
 // (PASSES 16-byte vectors per block) stay within 8 vectors
 constexpr int epilogue_blocks(int tn, int mi, int budget) {
@@ -272,6 +302,7 @@ __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI],
       live[t] = id < 16 * G && nn[t] < p.N;
     }
     const int mode = (p.bias2 ? 3 : 0) + p.act;   // act is 0..2 here (3 = GEGLU never takes this path)
+    stamp(p, 8);
 #pragma unroll
     for (int j0 = 0; j0 < MI; j0 += NB) {
       // residual loads of these blocks first: they are independent of the staging
@@ -294,6 +325,7 @@ __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI],
           for (int t = 0; t < PASSES; ++t)
             if (mm[jb][t] >= 0) resv[jb][t] = *reinterpret_cast<const f16x8*>(p.res + (size_t)mm[jb][t] * p.ldres + nn[t]);
       }
+      if (j0 == 0) stamp(p, 9);
 #pragma unroll
       for (int jb = 0; jb < NB; ++jb) {
         const int m = mrow[j0 + jb];
@@ -301,6 +333,7 @@ __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI],
         f32x4 accj[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) accj[i] = acc[i][j0 + jb];
+        if (dbg_on(p, 2048)) continue;          // ablation: no staging writes
         switch (mode) {
           case 0: stage_block<NI, TN, false, 0>(p, accj, bias, m, nb, fq, frow, sc); break;
           case 1: stage_block<NI, TN, false, 1>(p, accj, bias, m, nb, fq, frow, sc); break;
@@ -311,6 +344,8 @@ __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI],
         }
       }
       __builtin_amdgcn_wave_barrier();
+      if (j0 == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(p, 10); }
+      if (dbg_on(p, 1024)) continue;            // ablation: staging only
 #pragma unroll
       for (int jb = 0; jb < NB; ++jb) {
         const char* sc = scratch + jb * BLOCKB;
@@ -327,7 +362,7 @@ __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI],
               o[u] = (f16)(lo[u] + (float)resv[jb][t][u]);
               o[4 + u] = (f16)(hi[u] + (float)resv[jb][t][4 + u]);
             }
-            *reinterpret_cast<f16x8*>(p.y + (size_t)mm[jb][t] * p.ldy + nn[t]) = o;
+            if (!dbg_on(p, 512)) *reinterpret_cast<f16x8*>(p.y + (size_t)mm[jb][t] * p.ldy + nn[t]) = o;
             if (p.stats_out) {
 #pragma unroll
               for (int u = 0; u < 8; ++u) { const float f = (float)o[u]; ssum += f; ssq += f * f; }
@@ -351,8 +386,10 @@ __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI],
           }
         }
       }
+      if (j0 == 0) stamp(p, 11);
       __builtin_amdgcn_wave_barrier();        // the next round overwrites the scratch rows
     }
+    stamp(p, 12);
     return;
   }
 #pragma unroll

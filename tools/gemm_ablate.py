@@ -23,7 +23,9 @@ if len(sys.argv) > 5:
     print(f"{a.elapsed_time(e) / 40 * 1e3:.1f}")
 else:
     for flag, what in [(0, "full"), (32, "no epilogue"), (4, "no MFMAs"), (3, "operands from the zero page"), (8, "no DMAs after the prologue"),
-                       (16, "no fragment reads"), (36, "no MFMAs, no epilogue"), (35, "zero page + no epilogue")]:
+                       (16, "no fragment reads"), (36, "no MFMAs, no epilogue"), (35, "zero page + no epilogue"),
+                       (512, "epilogue without its global stores"), (1024, "epilogue: staging only"), (2048 + 512, "epilogue: no staging writes, no stores"),
+                       (2048 + 1024, "epilogue: set-up only")]:
         env = dict(os.environ, SDEO_DBG_GEMM=str(flag))
         r = subprocess.run([sys.executable, __file__] + sys.argv[1:5] + ["child"], env=env, capture_output=True, text=True)
         print(f"M{sys.argv[1]} N{sys.argv[2]} K{sys.argv[3]} tile {sys.argv[4]}  dbg {flag:2d} ({what}): {r.stdout.strip() or r.stderr[-200:]} us", flush=True)
