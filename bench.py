@@ -159,6 +159,8 @@ def main():
         x_Ts[u] = torch.cat([randn((1, 4, h, w), X_T_SEED + u * B + j) for j in range(B)]).to(dev)
 
     def one_image(index, timed=True):
+        if index not in x_Ts:       # the untimed profiling pass draws its own unit
+            x_Ts[index] = torch.cat([randn((1, 4, h, w), X_T_SEED + index * B + j) for j in range(B)]).to(dev)
         x_T = x_Ts[index]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
