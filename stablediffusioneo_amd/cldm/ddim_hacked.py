@@ -26,6 +26,10 @@ USE_GRAPH = os.environ.get("SDEO_GRAPH", "1") != "0"
 # Measured on MI355X (tools/step_replay.py): the per-step replay costs 6.99 ms per step inside the sampler loop against 6.78 ms
 # for back-to-back replays; the small kernels between two replays (cat, fill, copies, CFG / DDIM update) are what is in between.
 USE_LOOP_GRAPH = os.environ.get("SDEO_LOOP_GRAPH", "1") != "0"         # needs USE_GRAPH as well (checked per call)
+# DDIM steps per captured graph (0 = all remaining steps in ONE graph).  The rocprofv3 timeline of the one-graph loop (13.6 k kernel
+# nodes) shows seven ~0.7 ms chip-wide stalls per image, but they belong to the profiler: measured without it on one box, one graph
+# 6.63 ms per step, graphs of 4 / 2 / 1 steps 6.73 / 6.76 / 6.74 ms.
+LOOP_GRAPH_STEPS = max(0, int(os.environ.get("SDEO_LOOP_GRAPH_STEPS", "0")))
 
 
 def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=True):
@@ -210,7 +214,7 @@ class DDIMSampler(object):
         intermediates["x_inter"].append(img)             # index == total_steps - 1
         intermediates["pred_x0"].append(pred_x0)
         key = (rt.generation, tuple(img.shape), tuple(int(t) for t in time_range), float(scale), int(log_every_t),
-               tuple(float(v) for v in m.control_scales), bool(m.only_mid_control), getattr(self, "_schedule_key", None))
+               tuple(float(v) for v in m.control_scales), bool(m.only_mid_control), getattr(self, "_schedule_key", None), LOOP_GRAPH_STEPS)
         if getattr(self, "_loop_key", None) != key:
             self._loop_key = None
             self._loop_x = torch.empty_like(img)
@@ -218,27 +222,33 @@ class DDIMSampler(object):
             a_t, a_p, s1m = self.ddim_alphas, self.ddim_alphas_prev, self.ddim_sqrt_one_minus_alphas
             flags = HINT_CACHED | CONTEXT_CACHED
             torch.cuda.synchronize(dev)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                x, pred, kept_x, kept_p = self._loop_x, None, [], []
-                for i in range(1, total_steps):
-                    index = total_steps - i - 1
-                    t2 = torch.full((2 * b,), int(time_range[i]), device=dev, dtype=torch.long)
-                    eps2 = rt.apply_model(torch.cat([x, x]), None, t2, None, m.control_scales, m.only_mid_control, flags)
-                    x, pred = ops.cfg_ddim_step(x, eps2[:b], eps2[b:], scale, float(a_t[index]), float(a_p[index]), 0.0,
-                                                float(s1m[index]), noise=None)
-                    if index % log_every_t == 0:
-                        kept_x.append(x)
-                        kept_p.append(pred)
-            self._loop_graph, self._loop_out, self._loop_kept = g, x, (kept_x, kept_p)
+            graphs, kept_x, kept_p, last_pred = [], [], [], None
+            per_graph = LOOP_GRAPH_STEPS if LOOP_GRAPH_STEPS > 0 else total_steps
+            for first in range(1, total_steps, per_graph):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    x = self._loop_x
+                    for i in range(first, min(first + per_graph, total_steps)):
+                        index = total_steps - i - 1
+                        t2 = torch.full((2 * b,), int(time_range[i]), device=dev, dtype=torch.long)
+                        eps2 = rt.apply_model(torch.cat([x, x]), None, t2, None, m.control_scales, m.only_mid_control, flags)
+                        x, last_pred = ops.cfg_ddim_step(x, eps2[:b], eps2[b:], scale, float(a_t[index]), float(a_p[index]), 0.0,
+                                                         float(s1m[index]), noise=None)
+                        if index % log_every_t == 0:
+                            kept_x.append(x)
+                            kept_p.append(last_pred)
+                    self._loop_x.copy_(x)              # the next graph (and the caller) read the latent from the fixed buffer
+                graphs.append(g)
+            self._loop_graphs, self._loop_kept = graphs, (kept_x, kept_p)
             self._loop_key = key
         else:
             self._loop_x.copy_(img)
-        self._loop_graph.replay()
-        # the graph's tensors are overwritten by the next replay: hand out copies
+        for g in self._loop_graphs:
+            g.replay()
+        # the graphs' tensors are overwritten by the next replay: hand out copies
         intermediates["x_inter"].extend(t.clone() for t in self._loop_kept[0])
         intermediates["pred_x0"].extend(t.clone() for t in self._loop_kept[1])
-        return self._loop_out.clone(), intermediates
+        return self._loop_x.clone(), intermediates
 
     # ------------------------------------------------------------------------------------------ one step
     def _eps_pair(self, x, c, t, uc, scale):
