@@ -1,38 +1,46 @@
-"""How much throughput do K independent batch-1 pipelines (K handles, K host threads, K streams) get on one GPU?"""
-import os, sys, threading, time
+"""Do kernels of two HIP streams run concurrently on this device when each leaves most CUs idle?
+    python tools/concurrency_probe.py
+A chain of n small GroupNorm launches (16 workgroups, ~6 us each) on one stream vs two such chains on two streams."""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from stablediffusioneo_amd import spec as S
-from stablediffusioneo_amd.cldm.cldm import ControlLDM
-from stablediffusioneo_amd.cldm.ddim_hacked import DDIMSampler
-from stablediffusioneo_amd.runtime import SdeoRuntime
-from tests.common import make_hint, randn
+from stablediffusioneo_amd import ops
 
-K = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-IM = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-dev = torch.device("cuda", 0)
-pipes = []
-for k in range(K):
-    rt = SdeoRuntime(S.UNET_SD15, S.VAE_SD15, device=dev); rt.load_synthetic_device(0)
-    m = ControlLDM(rt); pipes.append((m, DDIMSampler(m), torch.cuda.Stream()))
-hint = make_hint(1, 512, 512).to(dev); cc = randn((1, 77, 768), 1).to(dev); cu = randn((1, 77, 768), 2).to(dev)
-cond = {"c_concat": [hint], "c_crossattn": [cc]}; unc = {"c_concat": [hint], "c_crossattn": [cu]}
-
-def work(k, n):
-    m, s, st = pipes[k]
-    with torch.cuda.stream(st):
-        for i in range(n):
-            z, _ = s.sample(20, 1, (4, 64, 64), cond, verbose=False, eta=0.0, unconditional_guidance_scale=9.0,
-                            unconditional_conditioning=unc, x_T=randn((1, 4, 64, 64), 7 + i).to(dev))
-            m.decode_first_stage_uint8(z)
-        st.synchronize()
-
-for k in range(K):
-    work(k, 1)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-ths = [threading.Thread(target=work, args=(k, IM)) for k in range(K)]
-[t.start() for t in ths]; [t.join() for t in ths]
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-print(f"K={K}: {K * IM / dt:.3f} images/s ({dt / IM * 1e3:.1f} ms per image per pipeline)")
+dev = "cuda"
+n = 200
+def chain(x, g, b):
+    for _ in range(n):
+        ops.groupnorm_nhwc(x, g, b, 32, 1e-5, True)
+xs = [torch.randn(2, 8, 8, 1280, device=dev).half() for _ in range(2)]
+g = torch.ones(1280, device=dev); b = torch.zeros(1280, device=dev)
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+def run(two):
+    torch.cuda.synchronize()
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    s1.wait_stream(torch.cuda.current_stream()); s2.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s1): chain(xs[0], g, b)
+    if two:
+        with torch.cuda.stream(s2): chain(xs[1], g, b)
+    torch.cuda.current_stream().wait_stream(s1); torch.cuda.current_stream().wait_stream(s2)
+    e.record(); torch.cuda.synchronize()
+    return a.elapsed_time(e) * 1e3
+for _ in range(2): run(True)
+one = min(run(False) for _ in range(3)); two = min(run(True) for _ in range(3))
+print(f"eager: one chain of {n}: {one:.0f} us ({one / n:.2f} us per launch); two chains on two streams: {two:.0f} us  -> ratio {two / one:.2f}")
+# the same under graph capture (no host in the way)
+def graphed(two):
+    g_ = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g_):
+        cur = torch.cuda.current_stream()
+        s1.wait_stream(cur); s2.wait_stream(cur)
+        with torch.cuda.stream(s1): chain(xs[0], g, b)
+        if two:
+            with torch.cuda.stream(s2): chain(xs[1], g, b)
+        cur.wait_stream(s1); cur.wait_stream(s2)
+    g_.replay(); torch.cuda.synchronize()
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); g_.replay(); e.record(); torch.cuda.synchronize()
+    return a.elapsed_time(e) * 1e3
+one, two = graphed(False), graphed(True)
+print(f"graph: one chain: {one:.0f} us ({one / n:.2f} us per launch); two chains: {two:.0f} us -> ratio {two / one:.2f}")
