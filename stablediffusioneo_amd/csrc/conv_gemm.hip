@@ -831,6 +831,7 @@ size_t conv_gemm_workspace_bytes(const ConvGemm& p) {
 }
 
 const char* conv_gemm_kernel_name(const ConvGemm& p) { return kTiles[make_plan(p).tile].name; }
+int conv_gemm_plan_splitk(const ConvGemm& p) { return make_plan(p).splitk; }
 
 template <typename K>
 static int launch_k(K kernel, int smem, bool* attr_done, const KP2& kp, int count, int tiles, hipStream_t stream, int threads = 256) {
@@ -994,7 +995,7 @@ static int prepare(const ConvGemm& p, Plan& pl, KP& kp) {
 }
 
 // launch `count` (1 or 2) problems that share plan `pl` (and the template instance: ups, fp8)
-static int dispatch(const Plan& pl, int ups, bool w8, const KP2& kp, int count, hipStream_t stream) {
+static int dispatch(const Plan& pl, int ups, bool w8, const KP2& kp, int count, hipStream_t stream, bool no_reduce = false) {
   const int tiles = pl.tiles_m * pl.tiles_n;
   int rc = 0;
   if (w8) {
@@ -1039,7 +1040,7 @@ static int dispatch(const Plan& pl, int ups, bool w8, const KP2& kp, int count, 
     default: return fail("conv_gemm: bad tile %d", pl.tile);
   }
   if (rc) return rc;
-  if (pl.splitk > 1) {
+  if (pl.splitk > 1 && !no_reduce) {
     const int64_t n = (int64_t)kp.k[0].M * (kp.k[0].N / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n, 256), count), dim3(256), 0, stream, kp);
     SDEO_HIP(hipGetLastError());
@@ -1051,11 +1052,11 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
   Plan pl;
   KP2 kk{};
   if (int rc = prepare(p, pl, kk.k[0])) return rc;
-  return dispatch(pl, p.ups, p.wscale != nullptr, kk, 1, stream);
+  return dispatch(pl, p.ups, p.wscale != nullptr, kk, 1, stream, p.no_reduce != 0);
 }
 
 bool conv_gemm_can_pair(const ConvGemm& a, const ConvGemm& b) {
-  if (key_of(a) != key_of(b) || a.S != b.S || a.pad != b.pad || a.Ho != b.Ho || a.Wo != b.Wo) return false;
+  if (key_of(a) != key_of(b) || a.S != b.S || a.pad != b.pad || a.Ho != b.Ho || a.Wo != b.Wo || a.no_reduce || b.no_reduce) return false;
   if (a.force_tile != b.force_tile || a.force_splitk != b.force_splitk) return false;
   const Plan pa = make_plan(a), pb = make_plan(b);
   return pa.tile == pb.tile && pa.splitk == pb.splitk && pa.nk == pb.nk && pa.tiles_m == pb.tiles_m && pa.tiles_n == pb.tiles_n;

@@ -31,6 +31,7 @@ struct ConvGemm {
                                // 3 GEGLU pair: W rows interleaved value/gate in blocks of 16, y gets N/2 columns v * gelu(g)
   int bias_per_row = 0;
   float scale = 1.0f;
+  int no_reduce = 0;           // split-K plans: leave the partial slabs in `workspace` (the consumer reduces them: GnReduce)
   int force_tile = -1;         // testing hook: tile config index
   int force_splitk = 0;
   // LayerNorm folded into the GEMM (see KP::ln_stats in conv_inl.h): x is used raw, w = W * gamma, bias = b + W beta,
@@ -60,6 +61,7 @@ int conv_gemm_stats_strips(const ConvGemm& p);
 int conv_gemm_read_stamps(unsigned long long* out, int n);
 int conv_halo_read_stamps(unsigned long long* out, int n);
 size_t conv_gemm_workspace_bytes(const ConvGemm& p);
+int conv_gemm_plan_splitk(const ConvGemm& p);       // split-K factor of the plan chosen for p
 // name of the kernel instantiation the launcher will pick (for profiles; matches the rocprof kernel name's template args)
 const char* conv_gemm_kernel_name(const ConvGemm& p);
 void conv_gemm_debug_force(int tile, int splitk);
@@ -79,12 +81,30 @@ int gn_chunks(int HW);
 int groupnorm_nhwc(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const float* beta, int B, int HW, int C,
                    int groups, float eps, int with_silu, float* partials, hipStream_t stream);
 
+// x of a GroupNorm given as the fp32 partial slabs of a split-K conv / GEMM that has not been reduced yet (conv_gemm with
+// `no_reduce`): the single-launch GroupNorm sums the slabs, applies the conv's epilogue and writes x itself -- the arithmetic of
+// splitk_reduce_kernel in the same order, so the bits are those of the two separate launches, with one launch boundary less
+struct GnReduce {
+  const float* ws = nullptr;       // [splitk][M][N] partial sums (M = B * HW rows, N = C columns); null = x is read as usual
+  int splitk = 0;
+  const float* bias = nullptr;     // [N]
+  const float* bias2 = nullptr;    // [B][ld_bias2]
+  int ld_bias2 = 0;
+  const f16* res = nullptr;        // [M][ldres]
+  int ldres = 0;
+  float scale = 1.0f;
+  int act = 0;
+  const float* wscale = nullptr;   // [N] (fp8 weights)
+};
 struct GnArgs {
   f16* y; const f16* x; const float* gamma; const float* beta; float* partials;
   int ldy, ldx, B, HW, C, groups;
   float eps;
   int with_silu;
+  GnReduce red{};                  // with red.ws set, `x` is where the reduced tensor is WRITTEN (and normalised from LDS)
 };
+// whether groupnorm_nhwc(a) runs as ONE launch with its slice in LDS (the only form that can take GnReduce)
+bool groupnorm_is_single_launch(const GnArgs& a);
 int groupnorm_nhwc(const GnArgs& a, hipStream_t stream);
 // two GroupNorm problems of one shape in one launch (pair launch, see conv_gemm_pair); distinct `partials` required
 bool groupnorm_can_pair(const GnArgs& a, const GnArgs& b);

@@ -271,6 +271,13 @@ struct sdeo_handle_s {
   bool use_control = true;
   // programs
   Program p_hint, p_ctx_cn, p_ctx_unet, p_cn, p_cn_export, p_ctrl_import, p_unet_enc, p_unet_dec, p_unet_noctrl, p_vae;
+  // the same four network programs with every [split-K conv, single-launch GroupNorm] pair fused (fuse_reduce_groupnorm): the
+  // GroupNorm sums the conv's partial slabs itself, the splitk_reduce launch between them disappears
+  Program f_cn, f_unet_enc, f_unet_dec, f_unet_noctrl;
+  bool fuse_rg = false;      // SDEO_FUSE_REDUCE_GN=1 / sdeo_debug_set_reduce_gn: run them (same bits).  Measured on one box: 6.71 ms per step
+                             // fused vs 6.69 ms unfused -- 31 launches fewer per pass, but the 64 workgroups of the GroupNorm read the
+                             // slabs slower than the reduce kernel's 160 - 640 did, so the saved boundaries are spent again
+  int fused_rg = 0;
   // ControlNet and UNet encoder + middle block as ONE program: same-shaped ops of the two share a launch (merge_pairs)
   Program p_pair;
   bool pair = false;         // SDEO_PAIR=1 runs it instead of the two programs on two streams.  Measured on MI355X (same box, batch 1,
@@ -923,6 +930,49 @@ static Program merge_pairs(Engine* e, const Program& a, const Program& b) {
   return out;
 }
 
+// ------------------------------------------------------------------------------------------------
+// [conv / GEMM on a split-K plan] -> [GroupNorm small enough for the single-launch kernel] (every ResBlock at the 16x16 and 8x8
+// levels: `openaimodel.py:255-275`): the GroupNorm kernel reads the conv's fp32 partial slabs, applies the conv's epilogue with
+// the arithmetic of splitk_reduce_kernel, writes the conv's output tensor and normalises it from LDS.  Same bits, one launch
+// boundary (~3 us, serial chip-wide: DESIGN.md section 12) less per pair.
+// ------------------------------------------------------------------------------------------------
+static Program fuse_reduce_groupnorm(Engine* eng, const Program& prog, int* count) {
+  Program out;
+  for (size_t i = 0; i < prog.size(); ++i) {
+    const Op& a = prog[i];
+    if (i + 1 < prog.size() && a.pd && a.pd->kind == PairDesc::CONV && prog[i + 1].pd && prog[i + 1].pd->kind == PairDesc::GN) {
+      const ConvGemm& cg = a.pd->cg;
+      const GnArgs& gn = prog[i + 1].pd->gn;
+      if (cg.y && !cg.y32 && !cg.bias_per_row && !cg.ln_stats && !cg.stats_out && cg.act != 3 && gn.x == cg.y && gn.ldx == cg.ldy &&
+          gn.C == cg.N && gn.B * gn.HW == cg.M && cg.Ho * cg.Wo == gn.HW && cg.N % 8 == 0 && (!cg.res || cg.ldres % 8 == 0) &&
+          a.pd->sel == prog[i + 1].pd->sel && conv_gemm_plan_splitk(cg) > 1 && groupnorm_is_single_launch(gn)) {
+        std::shared_ptr<PairDesc> pa = a.pd, pg = prog[i + 1].pd;
+        Op op([eng, pa, pg](hipStream_t s) {
+          ConvGemm q = pa->cg;
+          q.workspace = pa->sel ? eng->splitk_ws2 : eng->splitk_ws;
+          q.workspace_bytes = eng->splitk_ws_bytes;
+          if (pa->scale_host) q.scale = *pa->scale_host;
+          q.no_reduce = 1;
+          if (int rc = conv_gemm(q, s)) return rc;
+          GnArgs g = pg->gn;
+          g.partials = pg->sel ? eng->gn_ws2 : eng->gn_ws;
+          g.red.ws = q.workspace; g.red.splitk = conv_gemm_plan_splitk(q);
+          g.red.bias = q.bias; g.red.bias2 = q.bias2; g.red.ld_bias2 = q.ld_bias2; g.red.res = q.res; g.red.ldres = q.ldres;
+          g.red.scale = q.scale; g.red.act = q.act; g.red.wscale = q.wscale;
+          return groupnorm_nhwc(g, s);
+        });
+        op.key = a.key; op.flops = a.flops; op.bytes = a.bytes + prog[i + 1].bytes; op.tag = a.tag + " +gn";
+        out.push_back(std::move(op));
+        ++*count;
+        ++i;
+        continue;
+      }
+    }
+    out.push_back(a);
+  }
+  return out;
+}
+
 static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* max_splitk, size_t* max_gn, std::string* err) {
   const sdeo_config& c = e->cfg;
   const int N = e->N, h = e->lh, w = e->lw;
@@ -1258,7 +1308,7 @@ static void free_configured(Engine* e) {
   if (e->arena2) (void)hipFree(e->arena2);
   e->arena2 = nullptr;
   for (Program* p : {&e->p_hint, &e->p_ctx_cn, &e->p_ctx_unet, &e->p_cn, &e->p_cn_export, &e->p_ctrl_import, &e->p_unet_enc,
-                     &e->p_unet_dec, &e->p_unet_noctrl, &e->p_vae, &e->p_pair})
+                     &e->p_unet_dec, &e->p_unet_noctrl, &e->p_vae, &e->p_pair, &e->f_cn, &e->f_unet_enc, &e->f_unet_dec, &e->f_unet_noctrl})
     p->clear();
 }
 
@@ -1287,6 +1337,7 @@ int sdeo_create(const sdeo_config* cfg, sdeo_handle* out) {
   if (const char* at = getenv("SDEO_AUTOTUNE")) e->autotune = atoi(at) != 0;
   if (const char* ov = getenv("SDEO_OVERLAP")) e->overlap = atoi(ov) != 0;
   if (const char* pv = getenv("SDEO_PAIR")) e->pair = atoi(pv) != 0;
+  if (const char* fv = getenv("SDEO_FUSE_REDUCE_GN")) e->fuse_rg = atoi(fv) != 0;
   SDEO_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
   SDEO_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   SDEO_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
@@ -1479,6 +1530,11 @@ int sdeo_configure(sdeo_handle h, int n, int latent_h, int latent_w) {
                "sdeo_configure: arena plan not reproducible");
   }
   h->p_pair = merge_pairs(h, h->p_unet_enc, h->p_cn);
+  h->fused_rg = 0;
+  h->f_cn = fuse_reduce_groupnorm(h, h->p_cn, &h->fused_rg);
+  h->f_unet_enc = fuse_reduce_groupnorm(h, h->p_unet_enc, &h->fused_rg);
+  h->f_unet_dec = fuse_reduce_groupnorm(h, h->p_unet_dec, &h->fused_rg);
+  { int dummy = 0; h->f_unet_noctrl = fuse_reduce_groupnorm(h, h->p_unet_noctrl, &dummy); }
   if (getenv("SDEO_PAIR_REPORT"))
     fprintf(stderr, "SDEO_PAIR: %zu + %zu launches -> %d shared + %d single\n", h->p_unet_enc.size(), h->p_cn.size(), h->pair_launches,
             h->pair_singles);
@@ -1524,7 +1580,7 @@ int sdeo_controlnet_forward(sdeo_handle h, const float* x_noisy, const float* hi
   SDEO_CHECK(!hint_new || hint, "sdeo_controlnet_forward: hint required");
   SDEO_CHECK(!ctx_new || context, "sdeo_controlnet_forward: context required");
   if (int rc = stage_inputs(h, x_noisy, hint, timesteps, ctx_new ? context : nullptr, hint_new, 2, s)) return rc;
-  if (int rc = run(h, h->p_cn, s)) return rc;
+  if (int rc = run(h, h->fuse_rg ? h->f_cn : h->p_cn, s)) return rc;
   if (int rc = run(h, h->p_cn_export, s)) return rc;
   for (size_t i = 0; i < h->ctrl_elems.size(); ++i)
     if (controls[i]) if (int rc = copy_in(controls[i], h->out_ctrl[i], h->ctrl_elems[i] * 4, s)) return rc;
@@ -1548,10 +1604,10 @@ int sdeo_unet_forward(sdeo_handle h, const float* x_noisy, const int64_t* timest
       if (int rc = copy_in(h->in_ctrl[i], controls[i], h->ctrl_elems[i] * 4, s)) return rc;
     }
     if (int rc = run(h, h->p_ctrl_import, s)) return rc;
-    if (int rc = run(h, h->p_unet_enc, s)) return rc;
-    if (int rc = run(h, h->p_unet_dec, s)) return rc;
+    if (int rc = run(h, h->fuse_rg ? h->f_unet_enc : h->p_unet_enc, s)) return rc;
+    if (int rc = run(h, h->fuse_rg ? h->f_unet_dec : h->p_unet_dec, s)) return rc;
   } else {
-    if (int rc = run(h, h->p_unet_noctrl, s)) return rc;
+    if (int rc = run(h, h->fuse_rg ? h->f_unet_noctrl : h->p_unet_noctrl, s)) return rc;
   }
   return copy_in(eps, h->out_eps, (size_t)h->N * h->cfg.out_channels * h->lh * h->lw * 4, s);
 }
@@ -1570,7 +1626,7 @@ int sdeo_apply_model(sdeo_handle h, const float* x_noisy, const float* hint, con
   h->only_mid = only_mid_control;
   for (int i = 0; i < 13; ++i) h->scales[i] = host_control_scales ? host_control_scales[i] : 1.0f;
   if (no_control) {
-    if (int rc = run(h, h->p_unet_noctrl, s)) return rc;
+    if (int rc = run(h, h->fuse_rg ? h->f_unet_noctrl : h->p_unet_noctrl, s)) return rc;
   } else {
     if (h->pair) {
       if (int rc = run(h, h->p_pair, s)) return rc;
@@ -1578,15 +1634,15 @@ int sdeo_apply_model(sdeo_handle h, const float* x_noisy, const float* hint, con
       // fork: ControlNet on the side stream, UNet encoder + middle block on the caller's stream (capturable)
       SDEO_HIP(hipEventRecord(h->ev_fork, s));
       SDEO_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-      if (int rc = run(h, h->p_cn, h->side)) return rc;
+      if (int rc = run(h, h->fuse_rg ? h->f_cn : h->p_cn, h->side)) return rc;
       SDEO_HIP(hipEventRecord(h->ev_join, h->side));
-      if (int rc = run(h, h->p_unet_enc, s)) return rc;
+      if (int rc = run(h, h->fuse_rg ? h->f_unet_enc : h->p_unet_enc, s)) return rc;
       SDEO_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
     } else {
-      if (int rc = run(h, h->p_cn, s)) return rc;
-      if (int rc = run(h, h->p_unet_enc, s)) return rc;
+      if (int rc = run(h, h->fuse_rg ? h->f_cn : h->p_cn, s)) return rc;
+      if (int rc = run(h, h->fuse_rg ? h->f_unet_enc : h->p_unet_enc, s)) return rc;
     }
-    if (int rc = run(h, h->p_unet_dec, s)) return rc;
+    if (int rc = run(h, h->fuse_rg ? h->f_unet_dec : h->p_unet_dec, s)) return rc;
   }
   return copy_in(eps, h->out_eps, (size_t)h->N * h->cfg.out_channels * h->lh * h->lw * 4, s);
 }
@@ -1616,6 +1672,12 @@ int sdeo_debug_set_pair(sdeo_handle h, int on) {
   h->pair = on != 0;
   return 0;
 }
+int sdeo_debug_set_reduce_gn(sdeo_handle h, int on) {
+  SDEO_CHECK(h, "null handle");
+  h->fuse_rg = on != 0;
+  return 0;
+}
+int sdeo_debug_reduce_gn_count(sdeo_handle h) { return h ? h->fused_rg : -1; }
 int sdeo_debug_pair_counts(sdeo_handle h, int* shared, int* single) {
   SDEO_CHECK(h && shared && single, "null argument");
   *shared = h->pair_launches; *single = h->pair_singles;

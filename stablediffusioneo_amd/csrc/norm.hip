@@ -19,7 +19,13 @@ namespace sdeo {
 // upper bound of the statistics chunks per image (sizes the partial-sum workspace)
 // operands of one GroupNorm problem; a launch takes one or two problems of the same shape (pair launch, see KP2 in conv_inl.h):
 // batch entries >= Bper belong to the second
-struct GnOne { f16* y; const f16* x; const float* gamma; const float* beta; float* partials; int ldy, ldx; };
+struct GnOne {
+  f16* y; const f16* x; const float* gamma; const float* beta; float* partials; int ldy, ldx;
+  // single-launch kernel only: x arrives as split-K slabs (GnReduce in kernels.h); N = C, rows = B * HW
+  const float* ws; const float* rbias; const float* rbias2; const f16* rres; const float* rwscale;
+  int splitk, ld_bias2, ldres, act, rows, N;
+  float scale;
+};
 struct GnPair { GnOne k[2]; };
 
 int gn_chunks(int HW) { const int c = cdiv(HW, 8); return c > 128 ? 128 : (c < 1 ? 1 : c); }
@@ -278,12 +284,64 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const GnPair gp, int Bper,
 
   const f16* xb = x + ((size_t)b * HW) * ldx + c0;
   f16* yb = y + ((size_t)b * HW) * ldy + c0;
-  for (int k = 0; k < nsweep; ++k) {
-    const int pix = prow + k * P;
-    // lanes without a pixel fetch a valid dummy (the first pixel of their vector); they are masked below
-    const f16* src = (active && pix < HW) ? xb + (size_t)pix * ldx : x + c0 % 8;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(slice + (size_t)k * NT * 16 + wave_u * 1024), 16, 0, 0);
+  if (g1.ws) {
+    // x = the not-yet-reduced output of a split-K conv: sum the slabs and apply that conv's epilogue exactly as
+    // splitk_reduce_kernel does (same order of additions, same single rounding), keep the fp16 vector in LDS and write it to x
+    const size_t zs = (size_t)g1.rows * g1.N;
+    f32x4 bv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, b2[2] = {bv[0], bv[0]}, wsv[2] = {bv[0], bv[0]};
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      if (g1.rbias) bv[hh] = *reinterpret_cast<const f32x4*>(g1.rbias + c0 + 4 * hh);
+      if (g1.rbias2) b2[hh] = *reinterpret_cast<const f32x4*>(g1.rbias2 + (size_t)b * g1.ld_bias2 + c0 + 4 * hh);
+      if (g1.rwscale) wsv[hh] = *reinterpret_cast<const f32x4*>(g1.rwscale + c0 + 4 * hh);
+    }
+    for (int k = 0; k < nsweep; ++k) {
+      const int pix = prow + k * P;
+      f16x8 o = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (active && pix < HW) {
+        const size_t m = (size_t)b * HW + pix;
+        f16x8 rv = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (g1.rres) rv = *reinterpret_cast<const f16x8*>(g1.rres + m * g1.ldres + c0);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const float* src = g1.ws + m * g1.N + c0 + 4 * hh;
+          f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int z0 = 0; z0 < g1.splitk; z0 += 8) {
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              t[u] = (z0 + u < g1.splitk) ? *reinterpret_cast<const f32x4*>(src + (size_t)(z0 + u) * zs) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+          }
+          if (g1.rwscale) v *= wsv[hh];
+          v += bv[hh];
+          v += b2[hh];
+          if (g1.act == 1) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
+          } else if (g1.act == 2) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = quick_gelu_f(v[t]);
+          }
+          v *= g1.scale;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] += (float)rv[4 * hh + t];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) o[4 * hh + t] = (f16)v[t];
+        }
+        *reinterpret_cast<f16x8*>(const_cast<f16*>(xb) + (size_t)pix * ldx) = o;
+      }
+      *reinterpret_cast<f16x8*>(slice + (size_t)k * NT * 16 + (size_t)tid * 16) = o;
+    }
+  } else {
+    for (int k = 0; k < nsweep; ++k) {
+      const int pix = prow + k * P;
+      // lanes without a pixel fetch a valid dummy (the first pixel of their vector); they are masked below
+      const f16* src = (active && pix < HW) ? xb + (size_t)pix * ldx : x + c0 % 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(slice + (size_t)k * NT * 16 + wave_u * 1024), 16, 0, 0);
+    }
   }
   f32x4 gm[2], bt[2];
   gm[0] = *reinterpret_cast<const f32x4*>(gamma + c0);
@@ -413,7 +471,31 @@ static int gn_check(const GnArgs& a) {
   SDEO_CHECK(a.B > 0 && a.HW > 0 && a.C > 0, "groupnorm: empty tensor");
   SDEO_CHECK(a.groups > 0 && a.groups <= 64 && a.C % a.groups == 0, "groupnorm: C=%d not divisible into %d groups", a.C, a.groups);
   SDEO_CHECK(a.C % 8 == 0 && a.ldx % 8 == 0 && a.ldy % 8 == 0, "groupnorm: C=%d ldx=%d ldy=%d must be multiples of 8", a.C, a.ldx, a.ldy);
+  if (a.red.ws)
+    SDEO_CHECK(a.red.splitk >= 2 && (!a.red.res || a.red.ldres % 8 == 0) && a.red.act >= 0 && a.red.act <= 2,
+               "groupnorm: bad split-K input (splitk %d, ldres %d, act %d)", a.red.splitk, a.red.ldres, a.red.act);
   return 0;
+}
+
+// 0: two-launch path; 256 / 1024: threads of the single-launch kernel
+static int gn_fused_threads(const GnArgs& a) {
+  const int HW = a.HW, C = a.C, cpg = C / a.groups;
+  static const int two_pass = [] { const char* e = getenv("SDEO_GN_TWO_PASS"); return e ? atoi(e) : 0; }();
+  const int nvw = two_pass ? 0 : gn_fused_vecs(C, cpg);
+  if (nvw <= 0) return 0;
+  // small slices: 256 threads (more workgroups per CU); otherwise 1024 threads, if the slice fits in LDS
+  // Measured (tools/small_bench.py): one launch wins up to 16x16 pixels (6.1 vs 9.0 us at 8x8, 8.4 vs 9.5 at 16x16);
+  // from 32x32 on, the many-workgroup two-launch path is faster than one workgroup per part (9.9 vs 12.3 us).
+  // SDEO_GN_FUSED_MAX_HW overrides the crossover for measurements.
+  static const int max_hw = [] { const char* e = getenv("SDEO_GN_FUSED_MAX_HW"); return e ? atoi(e) : 256; }();
+  if (HW > max_hw) return 0;
+  if (cdiv(HW, 256 / nvw) <= 8 && gn_fused_smem<256>(HW, nvw) <= kGnFusedLdsCap) return 256;
+  if (cdiv(HW, 1024 / nvw) <= 60 && gn_fused_smem<1024>(HW, nvw) <= kGnFusedLdsCap) return 1024;
+  return 0;
+}
+
+bool groupnorm_is_single_launch(const GnArgs& a) {
+  return a.groups > 0 && a.C % a.groups == 0 && a.C % 8 == 0 && gn_fused_threads(a) != 0;
 }
 
 static int gn_dispatch(const GnArgs& a, const GnPair& gp, int count, hipStream_t stream) {
@@ -421,22 +503,12 @@ static int gn_dispatch(const GnArgs& a, const GnPair& gp, int count, hipStream_t
   const float eps = a.eps;
   const int cpg = C / groups;
   {
-    static const int two_pass = [] { const char* e = getenv("SDEO_GN_TWO_PASS"); return e ? atoi(e) : 0; }();
-    const int nvw = two_pass ? 0 : gn_fused_vecs(C, cpg);
-    if (nvw > 0) {
-      // small slices: 256 threads (more workgroups per CU); otherwise 1024 threads, if the slice fits in LDS
-      // Measured (tools/small_bench.py): one launch wins up to 16x16 pixels (6.1 vs 9.0 us at 8x8, 8.4 vs 9.5 at 16x16);
-      // from 32x32 on, the many-workgroup two-launch path is faster than one workgroup per part (9.9 vs 12.3 us).
-      // SDEO_GN_FUSED_MAX_HW overrides the crossover for measurements.
-      static const int max_hw = [] { const char* e = getenv("SDEO_GN_FUSED_MAX_HW"); return e ? atoi(e) : 256; }();
-      if (HW <= max_hw) {
-        if (cdiv(HW, 256 / nvw) <= 8 && gn_fused_smem<256>(HW, nvw) <= kGnFusedLdsCap)
-          return launch_gn_fused<256>(gp, count, B, HW, C, cpg, nvw, eps, with_silu, stream);
-        if (cdiv(HW, 1024 / nvw) <= 60 && gn_fused_smem<1024>(HW, nvw) <= kGnFusedLdsCap)
-          return launch_gn_fused<1024>(gp, count, B, HW, C, cpg, nvw, eps, with_silu, stream);
-      }
-    }
+    const int nt = gn_fused_threads(a);
+    const int nvw = gn_fused_vecs(C, cpg);
+    if (nt == 256) return launch_gn_fused<256>(gp, count, B, HW, C, cpg, nvw, eps, with_silu, stream);
+    if (nt == 1024) return launch_gn_fused<1024>(gp, count, B, HW, C, cpg, nvw, eps, with_silu, stream);
   }
+  SDEO_CHECK(!a.red.ws, "groupnorm: split-K slabs as input need the single-launch kernel (HW=%d C=%d)", HW, C);
   const int nvb = gn_vec_per_block(C, groups);
   SDEO_CHECK(nvb > 0, "groupnorm: unsupported channel split C=%d groups=%d", C, groups);
   const int parts = (C / 8) / nvb;
@@ -458,7 +530,10 @@ static int gn_dispatch(const GnArgs& a, const GnPair& gp, int count, hipStream_t
   return 0;
 }
 
-static GnOne gn_one(const GnArgs& a) { return GnOne{a.y, a.x, a.gamma, a.beta, a.partials, a.ldy, a.ldx}; }
+static GnOne gn_one(const GnArgs& a) {
+  return GnOne{a.y, a.x, a.gamma, a.beta, a.partials, a.ldy, a.ldx, a.red.ws, a.red.bias, a.red.bias2, a.red.res, a.red.wscale,
+               a.red.splitk, a.red.ld_bias2, a.red.ldres, a.red.act, a.B * a.HW, a.C, a.red.scale};
+}
 
 int groupnorm_nhwc(const GnArgs& a, hipStream_t stream) {
   if (int rc = gn_check(a)) return rc;
@@ -468,7 +543,7 @@ int groupnorm_nhwc(const GnArgs& a, hipStream_t stream) {
 }
 
 bool groupnorm_can_pair(const GnArgs& a, const GnArgs& b) {
-  return a.B == b.B && a.HW == b.HW && a.C == b.C && a.groups == b.groups && a.eps == b.eps && a.with_silu == b.with_silu;
+  return !a.red.ws && !b.red.ws && a.B == b.B && a.HW == b.HW && a.C == b.C && a.groups == b.groups && a.eps == b.eps && a.with_silu == b.with_silu;
 }
 
 int groupnorm_nhwc_pair(const GnArgs& a, const GnArgs& b, hipStream_t stream) {
