@@ -340,7 +340,7 @@ void attention_kernel(const AP2 pp) {
 template <int DS>
 __global__ __launch_bounds__(256, 1) void attention_wide_kernel(const AP p) {
   constexpr int D = 4 * DS;                                   // head dim
-  constexpr int KS16 = DS / 16;                               // QK^T k-steps per wave
+  constexpr int KS16 = DS / 16;                               // QK^T k-steps per wave (even)
   constexpr int DT = DS / 32;                                 // 32-row tiles of O^T per wave
   constexpr int KROW = D * 2 + 16;                            // K tile row bytes: odd multiple of 16
   constexpr int VROW = D * 2 + 64;                            // V tile row bytes: 64 (mod 256), see attn_vrow
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(const AP p) {
   static_assert(KROW % 32 == 16 && VROW % 256 == 64 && (32 * CH) % 256 == 0, "tile geometry");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* xch = smem + 2 * STAGE;                               // partial-score exchange: [wave][lane][16] fp32 (16 KB)
+  char* xch = smem + 2 * STAGE;                               // partial-score exchange: [wave][4][lane] f32x4 (16 KB)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lq = lane & 31, lh = lane >> 5;
@@ -374,29 +374,36 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(const AP p) {
   const f16* vbase = p.v + (size_t)b * p.TkSv * p.ldv + h * D;
   const int ntiles = (p.Tk + 31) / 32;
   const f16x8 zero8 = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-  f16x8 kr[PASS], vr[PASS];
-  auto load_tile = [&](int kt) {
+  // K / V tiles are register-staged two tiles ahead (two register sets): with one workgroup per CU and one wave per SIMD nothing
+  // else hides a global round trip, and one tile of compute (~1 us) is shorter than it (measured: 2.7 us per tile with the
+  // loads issued one tile ahead)
+  f16x8 kr[2][PASS], vr[2][PASS];
+  auto load_tile = [&](auto SET, int kt) {
+    constexpr int rs = SET.value;
 #pragma unroll
     for (int i = 0; i < PASS; ++i) {
       const int it = tid + i * 256;
       const int row = it / CH, c = it - row * CH;
       const int key = kt * 32 + row;
       const bool ok = key < p.Tk;                            // rows >= Tk: K zero (masked anyway), V zero (P is 0 there)
-      kr[i] = ok ? *reinterpret_cast<const f16x8*>(kbase + (size_t)key * p.ldk + c * 8) : zero8;
-      vr[i] = ok ? *reinterpret_cast<const f16x8*>(vbase + (size_t)key * p.ldv + c * 8) : zero8;
+      kr[rs][i] = ok ? *reinterpret_cast<const f16x8*>(kbase + (size_t)key * p.ldk + c * 8) : zero8;
+      vr[rs][i] = ok ? *reinterpret_cast<const f16x8*>(vbase + (size_t)key * p.ldv + c * 8) : zero8;
     }
   };
-  auto store_tile = [&](int stage) {
+  auto store_tile = [&](auto SET, int stage) {
+    constexpr int rs = SET.value;
     char* ks_ = smem + stage * STAGE;
     char* vs_ = ks_ + KBYTES;
 #pragma unroll
     for (int i = 0; i < PASS; ++i) {
       const int it = tid + i * 256;
       const int row = it / CH, c = it - row * CH;
-      *reinterpret_cast<f16x8*>(ks_ + row * KROW + c * 16) = kr[i];
-      *reinterpret_cast<f16x8*>(vs_ + row * VROW + c * 16) = vr[i];
+      *reinterpret_cast<f16x8*>(ks_ + row * KROW + c * 16) = kr[rs][i];
+      *reinterpret_cast<f16x8*>(vs_ + row * VROW + c * 16) = vr[rs][i];
     }
   };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
 
   f32x16 o[DT];
 #pragma unroll
@@ -405,30 +412,33 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(const AP p) {
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  load_tile(0);
-  store_tile(0);
+  load_tile(S0{}, 0);
+  store_tile(S0{}, 0);
+  if (ntiles > 1) load_tile(S1{}, 1);                 // set 1 carries the odd tiles, set 0 the even ones
+  if (ntiles > 2) load_tile(S0{}, 2);
   __syncthreads();
 
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < ntiles;
-    if (more) load_tile(kt + 1);
+  auto compute = [&](int kt, int cur) __attribute__((always_inline)) {
     const char* ks_ = smem + cur * STAGE;
     const char* vs_ = ks_ + KBYTES;
 
     // ---- partial S^T over this wave's channel slice
-    f32x16 s;
+    f32x16 s, s1;                                     // two accumulation chains: a 32x32x16 MFMA has 16 passes of latency
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
-    for (int ks = 0; ks < KS16; ++ks) {
-      const f16x8 kf = *reinterpret_cast<const f16x8*>(ks_ + lq * KROW + (c0 / 8 + ks * 2 + lh) * 16);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+    for (int ks = 0; ks < KS16; ks += 2) {
+      const f16x8 kf0 = *reinterpret_cast<const f16x8*>(ks_ + lq * KROW + (c0 / 8 + ks * 2 + lh) * 16);
+      const f16x8 kf1 = *reinterpret_cast<const f16x8*>(ks_ + lq * KROW + (c0 / 8 + ks * 2 + 2 + lh) * 16);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf0, qf[ks], s, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1, qf[ks + 1], s1, 0, 0, 0);
     }
-    {
-      f32x4* dst = reinterpret_cast<f32x4*>(xch + (wave * 64 + lane) * 64);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) dst[g] = f32x4{s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]};
+    for (int r = 0; r < 16; ++r) s[r] += s1[r];
+    {
+      f32x4* dst = reinterpret_cast<f32x4*>(xch) + wave * 256 + lane;       // [wave][4 register groups][lane]: lane-contiguous
+#pragma unroll
+      for (int g = 0; g < 4; ++g) dst[g * 64] = f32x4{s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]};
     }
     __syncthreads();
     // ---- full scores: the four partials in a fixed order (every wave computes the same bits)
@@ -436,10 +446,10 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(const AP p) {
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      const f32x4* src = reinterpret_cast<const f32x4*>(xch + (w * 64 + lane) * 64);
+      const f32x4* src = reinterpret_cast<const f32x4*>(xch) + w * 256 + lane;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 v = src[g];
+        const f32x4 v = src[g * 64];
         s[4 * g] += v[0]; s[4 * g + 1] += v[1]; s[4 * g + 2] += v[2]; s[4 * g + 3] += v[3];
       }
     }
@@ -486,8 +496,20 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(const AP p) {
         o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
       }
     }
-    if (more) store_tile(cur ^ 1);
-    __syncthreads();                                           // buffer swap; the exchange area is free again
+  };
+  // at the end of a tile the NEXT tile (loaded two iterations ago) goes from registers to the other LDS buffer and the freed
+  // register set takes the loads of the tile after that; the closing barrier also frees the exchange area
+  for (int kt = 0; kt < ntiles; kt += 2) {
+    compute(kt, 0);
+    if (kt + 1 < ntiles) store_tile(S1{}, 1);
+    if (kt + 3 < ntiles) load_tile(S1{}, kt + 3);
+    __syncthreads();
+    if (kt + 1 < ntiles) {
+      compute(kt + 1, 1);
+      if (kt + 2 < ntiles) store_tile(S0{}, 0);
+      if (kt + 4 < ntiles) load_tile(S0{}, kt + 4);
+      __syncthreads();
+    }
   }
 
   if (qvalid) {
