@@ -43,7 +43,10 @@ struct AP {
   int causal;        // 1: key j is visible to query t only when j <= t (CLIP text transformer)
 };
 
-struct AP2 { AP k[2]; };
+#ifndef SDEO_PAIR_SLOTS
+#define SDEO_PAIR_SLOTS 2
+#endif
+struct AP2 { AP k[SDEO_PAIR_SLOTS]; };
 
 // KS = 1: four waves, each owning 32 queries and walking all keys.  KS = 2 ("key split"): eight waves, the two waves of a
 // pair own the same 32 queries and each takes one 32-key half of every staged tile, so the serial per-tile chain
@@ -619,7 +622,7 @@ int attention(const AttnArgs& a, hipStream_t stream) {
 }
 
 bool attention_can_pair(const AttnArgs& a, const AttnArgs& b) {
-  return a.d <= 160 && a.B == b.B && a.H == b.H && a.Tq == b.Tq && a.Tk == b.Tk && a.d == b.d && a.causal == b.causal;
+  return SDEO_PAIR_SLOTS == 2 && a.d <= 160 && a.B == b.B && a.H == b.H && a.Tq == b.Tq && a.Tk == b.Tk && a.d == b.d && a.causal == b.causal;
 }
 
 int attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t stream) {
@@ -629,7 +632,7 @@ int attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t stream) {
   }
   AP2 ap{};
   if (int rc = attn_prepare(ap.k[0], a)) return rc;
-  if (int rc = attn_prepare(ap.k[1], b)) return rc;
+  if (int rc = attn_prepare(ap.k[SDEO_PAIR_SLOTS - 1], b)) return rc;
   return attn_dispatch(ap, 2, a.B, stream);
 }
 

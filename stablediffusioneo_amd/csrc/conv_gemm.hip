@@ -1056,6 +1056,7 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
 }
 
 bool conv_gemm_can_pair(const ConvGemm& a, const ConvGemm& b) {
+  if (SDEO_PAIR_SLOTS != 2) return false;
   if (key_of(a) != key_of(b) || a.S != b.S || a.pad != b.pad || a.Ho != b.Ho || a.Wo != b.Wo || a.no_reduce || b.no_reduce) return false;
   if (a.force_tile != b.force_tile || a.force_splitk != b.force_splitk) return false;
   const Plan pa = make_plan(a), pb = make_plan(b);
@@ -1070,7 +1071,7 @@ int conv_gemm_pair(const ConvGemm& a, const ConvGemm& b, hipStream_t stream) {
   Plan pl, pl2;
   KP2 kk{};
   if (int rc = prepare(a, pl, kk.k[0])) return rc;
-  if (int rc = prepare(b, pl2, kk.k[1])) return rc;
+  if (int rc = prepare(b, pl2, kk.k[SDEO_PAIR_SLOTS - 1])) return rc;
   return dispatch(pl, a.ups, a.wscale != nullptr, kk, 2, stream);
 }
 

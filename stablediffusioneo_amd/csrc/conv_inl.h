@@ -49,7 +49,10 @@ struct KP {
 // What a kernel receives: one problem, or two independent problems of the SAME plan (grid, tile, split-K, template instance)
 // run by one launch, blockIdx.y selecting the problem ("pair launch": the ControlNet and the UNet encoder execute the same
 // sequence of shapes on different weights and activations, and at batch 1 a launch rarely fills the chip by itself).
-struct KP2 { KP k[2]; };
+#ifndef SDEO_PAIR_SLOTS
+#define SDEO_PAIR_SLOTS 2
+#endif
+struct KP2 { KP k[SDEO_PAIR_SLOTS]; };
 
 // Ablation / stamp switches exist only in the measurement build: in the production library dbg_on() is the constant false and
 // every branch on it (and the stamp code) is compiled out of the K loops.

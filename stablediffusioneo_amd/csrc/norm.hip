@@ -26,7 +26,10 @@ struct GnOne {
   int splitk, ld_bias2, ldres, act, rows, N;
   float scale;
 };
-struct GnPair { GnOne k[2]; };
+#ifndef SDEO_PAIR_SLOTS
+#define SDEO_PAIR_SLOTS 2
+#endif
+struct GnPair { GnOne k[SDEO_PAIR_SLOTS]; };
 
 int gn_chunks(int HW) { const int c = cdiv(HW, 8); return c > 128 ? 128 : (c < 1 ? 1 : c); }
 
@@ -538,12 +541,12 @@ static GnOne gn_one(const GnArgs& a) {
 int groupnorm_nhwc(const GnArgs& a, hipStream_t stream) {
   if (int rc = gn_check(a)) return rc;
   GnPair gp{};
-  gp.k[0] = gp.k[1] = gn_one(a);
+  gp.k[0] = gp.k[SDEO_PAIR_SLOTS - 1] = gn_one(a);
   return gn_dispatch(a, gp, 1, stream);
 }
 
 bool groupnorm_can_pair(const GnArgs& a, const GnArgs& b) {
-  return !a.red.ws && !b.red.ws && a.B == b.B && a.HW == b.HW && a.C == b.C && a.groups == b.groups && a.eps == b.eps && a.with_silu == b.with_silu;
+  return SDEO_PAIR_SLOTS == 2 && !a.red.ws && !b.red.ws && a.B == b.B && a.HW == b.HW && a.C == b.C && a.groups == b.groups && a.eps == b.eps && a.with_silu == b.with_silu;
 }
 
 int groupnorm_nhwc_pair(const GnArgs& a, const GnArgs& b, hipStream_t stream) {
@@ -555,7 +558,7 @@ int groupnorm_nhwc_pair(const GnArgs& a, const GnArgs& b, hipStream_t stream) {
   if (int rc = gn_check(b)) return rc;
   GnPair gp{};
   gp.k[0] = gn_one(a);
-  gp.k[1] = gn_one(b);
+  gp.k[SDEO_PAIR_SLOTS - 1] = gn_one(b);
   return gn_dispatch(a, gp, 2, stream);
 }
 
