@@ -11,9 +11,10 @@ resident in HBM.  Images are sharded over ranks by image index (no data-path col
 gathered once with RCCL inside the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline     -- the dominant (kernel, problem shape) pair by device time of one profiled image: algorithmic FLOPs of its
-                  launches / their summed HIP-event durations, against the dense fp16 MFMA peak (2.5 PFLOP/s); `traffic` is
-                  the committed rocprofv3 --pmc measurement of the same pair (profiles/r01_traffic.json).
+  roofline     -- the conv / GEMM kernel family of one profiled image (the group holding most of the device time): algorithmic FLOPs
+                  of its launches / their summed HIP-event durations, against the dense fp16 MFMA peak (2.5 PFLOP/s); `traffic` =
+                  HBM-side bytes of one DDIM step from the committed rocprofv3 --pmc passes (profiles/r0N_step_counters.json);
+                  the single (kernel, shape) pair with the most device time is kept under `dominant_pair`.
   cpu_baseline -- the oracle (oracle/sd_oracle.py = fp32 PyTorch restatement of the reference path, "port") timed
                   on this host's cores on a bounded sample (N=1 only).
 """
@@ -115,8 +116,39 @@ def cpu_baseline(res, ddim_steps, scale):
                                     "measured in full", "seconds_per_image": round(d1, 3), "images_per_s": round(1.0 / d1, 5)}}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without an external launcher: start N copies of this command, one per GPU, with the
+    torch.distributed environment set (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), BEFORE this process has touched
+    a device (it never does: the parent only waits).  Rank 0's stdout (the one JSON line) is passed through; the exit code is the
+    worst child's.  Under `python -m torch.distributed.run` the environment is already there and nothing is spawned."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this platform (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))
+    if os.environ.get("SDEO_BENCH_ECHO_ENV"):      # launcher self-test (tests/test_sharding_cpu.py): report the rank environment, touch no device
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}),
+              file=open(os.environ["SDEO_BENCH_ECHO_ENV"] + "." + os.environ.get("RANK", "0"), "w"))
+        return
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -199,8 +231,12 @@ def main():
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if dist:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tall = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(tall, tmax)                 # bookkeeping only (after the timed region): every rank's own wall time
+        per_rank = [round(a.steps * B / float(t.item()), 4) for t in tall]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     loop_ms = sum(e0.elapsed_time(e1) for e0, e1 in loop_ev) / max(len(loop_ev), 1)
@@ -243,23 +279,37 @@ def main():
                         "tflops": round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 1) if e["flops"] else None,
                         "frac_of_mfma_peak": round(e["flops"] / (e["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS_F16, 4) if e["flops"] else None,
                         "share_of_device_time": round(e["ms"] / tot_ms, 3)} for f, e in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
-        traffic, tnote = None, None
-        for tname in ("r02_traffic.json", "r01_traffic.json"):
-            tpath = os.path.join(ROOT, "profiles", tname)
-            if os.path.exists(tpath):          # PMC numbers cannot be taken inside this process: committed rocprofv3 --pmc result
-                tj = json.load(open(tpath)).get(dom["kernel"])
-                if tj:
-                    traffic, tnote = tj["traffic_bytes"], tj["shape"] + f" ({tname})"
-                    break
-        step_counters = None
-        spath = os.path.join(ROOT, "profiles", "r02_step_counters.json")
-        if os.path.exists(spath):
-            step_counters = json.load(open(spath)).get("summary")
-        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_TFLOPS_F16, 4), "traffic": traffic, "traffic_measured_on": tnote,
-                "kernel": dom["kernel"],
-                "launches_per_image": dom["launches"], "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2),
-                "share_of_device_time": round(dom["total_ms"] / tot_ms, 3),
+        def committed(*names):           # newest committed rocprofv3 result of that kind (PMC numbers cannot be taken in this process)
+            for nm in names:
+                pth = os.path.join(ROOT, "profiles", nm)
+                if os.path.exists(pth):
+                    return json.load(open(pth)), nm
+            return None, None
+        tj, tname = committed("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
+        pair_traffic, tnote = None, None
+        if tj and tj.get(dom["kernel"]):
+            pair_traffic, tnote = tj[dom["kernel"]]["traffic_bytes"], tj[dom["kernel"]]["shape"] + f" ({tname})"
+        sj, sname = committed("r03_step_counters.json", "r02_step_counters.json")
+        step_counters = sj.get("summary") if sj else None
+        step_traffic = None
+        if step_counters:          # HBM-side bytes of ONE DDIM step (FETCH_SIZE x 2 + WRITE_SIZE, eager single-stream counter pass)
+            step_traffic = int((step_counters.get("hbm_read_GB_per_step", 0) + step_counters.get("hbm_write_GB_per_step", 0)) * 1e9) or None
+        # The headline fraction is that of the conv / GEMM FAMILY (all implicit-GEMM, halo-conv and GEMM launches of the image: the
+        # group that holds most of the device time), not of the single best (kernel, shape) pair -- the pair is kept under
+        # `dominant_pair`.  achieved = sum of algorithmic FLOP of the family's launches / sum of their HIP-event durations.
+        cg = fam["conv_gemm"]
+        cg_ach = cg["flops"] / (cg["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(cg_ach, 2), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
+                "frac": round(cg_ach / PEAK_TFLOPS_F16, 4),
+                "traffic": step_traffic,
+                "traffic_is": f"HBM-side bytes of one DDIM step, all kernels (FETCH_SIZE x 2 + WRITE_SIZE; {sname}); per-kernel passes: profiles/r03_gemm_counters.json",
+                "kernel": "conv / GEMM family: conv_gemm_dma_kernel<*> + conv3x3_halo_kernel<*> + conv_gemm_kernel<*> (every F.conv2d / F.linear of the path)",
+                "launches_per_image": cg["launches"], "avg_launch_us": round(cg["ms"] * 1e3 / cg["launches"], 2),
+                "share_of_device_time": round(cg["ms"] / tot_ms, 3),
+                "dominant_pair": {"kernel": dom["kernel"], "achieved": round(ach, 2), "frac": round(ach / PEAK_TFLOPS_F16, 4),
+                                  "launches_per_image": dom["launches"], "avg_launch_us": round(dom["total_ms"] * 1e3 / dom["launches"], 2),
+                                  "share_of_device_time": round(dom["total_ms"] / tot_ms, 3),
+                                  "traffic": pair_traffic, "traffic_measured_on": tnote},
                 "launches_per_image_all_kernels": sum(k["launches"] for k in prof),
                 "families": families,
                 "whole_step_counters": step_counters,
@@ -291,6 +341,7 @@ def main():
         }
         if gather_ms is not None:
             out["latent_all_gather_ms"] = round(gather_ms, 3)      # the only collective of the job (rank 0's wall time, sync to sync)
+            out["per_rank_images_per_s"] = per_rank
         if golden_check:
             out["output_check"] = golden_check
         if roof:

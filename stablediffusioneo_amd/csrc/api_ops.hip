@@ -32,7 +32,6 @@ extern "C" {
 const char* sdeo_last_error(void) { return g_last_error.c_str(); }
 int sdeo_version(void) { return 100; }
 void sdeo_debug_force_gemm_plan(int tile, int splitk) { conv_gemm_debug_force(tile, splitk); }
-void sdeo_debug_set_gemm_persist(int on) { conv_gemm_set_persist(on); }
 void sdeo_debug_force_gemm_order(int order) { conv_gemm_debug_force_order(order); }
 void sdeo_set_tuned_gemm_plan(const int* key10, int tile, int splitk) { conv_gemm_set_tuned(key10, tile, splitk); }
 const char* sdeo_tuned_gemm_plans_json(void) {
@@ -54,10 +53,17 @@ int sdeo_groupnorm_nhwc_f16(void* y, const void* x, const float* gamma, const fl
 
 static thread_local const void* g_next_q8 = nullptr;
 static thread_local const float* g_next_q8_scale = nullptr;
-static void take_fp8(ConvGemm& p) {           // sdeo_debug_next_weights_fp8: one-shot
-  if (!g_next_q8) return;
-  p.w = (const f16*)g_next_q8; p.wscale = g_next_q8_scale; p.ldw = p.K;
+// sdeo_debug_next_weights_fp8 is one-shot: every conv / GEMM entry point disarms it FIRST (before any validation can fail), so a
+// rejected call can never leave it armed for an unrelated later one
+struct Fp8Arm { const void* q; const float* s; };
+static Fp8Arm disarm_fp8() {
+  Fp8Arm a{g_next_q8, g_next_q8_scale};
   g_next_q8 = nullptr; g_next_q8_scale = nullptr;
+  return a;
+}
+static void take_fp8(ConvGemm& p, const Fp8Arm& a) {
+  if (!a.q) return;
+  p.w = (const f16*)a.q; p.wscale = a.s; p.ldw = p.K;
 }
 
 static int fill_conv(ConvGemm& p, int n, int h, int w, int cin, int cout, int ksize, int stride, int upsample2x) {
@@ -111,12 +117,36 @@ const char* sdeo_debug_conv2d_kernel_name(int n, int h, int w, int cin, int cout
 int sdeo_conv2d_nhwc_f16(void* y, const void* x, const void* w_krsc, const float* bias, const float* bias2, const void* res,
                          int n, int h, int w, int cin, int cout, int ksize, int stride, int upsample2x, int act, float scale,
                          void* workspace, size_t workspace_bytes, void* stream) {
+  const Fp8Arm arm = disarm_fp8();
   ConvGemm p;
   if (int rc = fill_conv(p, n, h, w, cin, cout, ksize, stride, upsample2x)) return rc;
   p.x = (const f16*)x; p.w = (const f16*)w_krsc; p.y = (f16*)y; p.bias = bias; p.bias2 = bias2; p.res = (const f16*)res;
   p.act = act; p.scale = scale; p.workspace = (float*)workspace; p.workspace_bytes = workspace_bytes;
-  take_fp8(p);
+  take_fp8(p, arm);
   return conv_gemm(p, S(stream));
+}
+
+// conv2d whose epilogue emits the GroupNorm partials of its output, followed by the normalise-only GroupNorm that consumes them
+// (the [conv -> GroupNorm] pairs of the networks, csrc/net.hip).  *slots = entries per image the plan writes; 0 = this shape's plan
+// cannot emit them (nothing is launched then).  partials >= n * slots * groups * 2 floats (+ n * groups * 2 when slots > 128).
+int sdeo_debug_conv2d_gn_f16(void* ynorm, void* y, const void* x, const void* w_krsc, const float* bias, const void* res, int n, int h,
+                             int w, int cin, int cout, int ksize, int stride, int upsample2x, const float* gamma, const float* beta,
+                             int groups, float eps, int with_silu, float* partials, size_t partial_floats, int* slots, void* stream) {
+  (void)disarm_fp8();
+  SDEO_CHECK(slots && groups > 0 && cout % groups == 0, "conv2d_gn: bad arguments");
+  ConvGemm p;
+  if (int rc = fill_conv(p, n, h, w, cin, cout, ksize, stride, upsample2x)) return rc;
+  p.x = (const f16*)x; p.w = (const f16*)w_krsc; p.y = (f16*)y; p.bias = bias; p.res = (const f16*)res;
+  const int cpg = cout / groups;
+  *slots = conv_gemm_gn_slots(p, cpg);
+  if (*slots <= 0) { *slots = 0; return 0; }
+  const size_t need = (size_t)n * *slots * groups * 2, fold = *slots > 128 ? (size_t)n * groups * 2 : 0;
+  SDEO_CHECK(partials && partial_floats >= need + fold, "conv2d_gn: partials buffer too small");
+  p.gn_out = partials; p.gn_cpg = cpg; p.gn_slots = *slots; p.gn_groups = groups;
+  if (int rc = conv_gemm(p, S(stream))) return rc;
+  GnArgs g{(f16*)ynorm, (const f16*)y, gamma, beta, partials + need, cout, cout, n, p.Ho * p.Wo, cout, groups, eps, with_silu};
+  g.ext_partials = partials; g.ext_nsc = *slots;
+  return groupnorm_nhwc(g, S(stream));
 }
 
 static void fill_gemm(ConvGemm& p, int m, int n, int k) {
@@ -133,6 +163,7 @@ size_t sdeo_gemm_workspace_bytes(int m, int n, int k) {
 int sdeo_gemm_f16(void* y, int ldy, const void* x, int ldx, const void* w, int ldw, const float* bias, const void* res,
                   int ldres, int m, int n, int k, int act, float scale, int out_f32, int bias_per_row, void* workspace,
                   size_t workspace_bytes, void* stream) {
+  const Fp8Arm arm = disarm_fp8();
   ConvGemm p;
   fill_gemm(p, m, n, k);
   p.x = (const f16*)x; p.w = (const f16*)w; p.bias = bias; p.res = (const f16*)res;
@@ -140,7 +171,7 @@ int sdeo_gemm_f16(void* y, int ldy, const void* x, int ldx, const void* w, int l
   p.ldx = ldx; p.ldw = ldw; p.ldy = ldy; p.ldres = ldres;
   p.act = act; p.scale = scale; p.bias_per_row = bias_per_row;
   p.workspace = (float*)workspace; p.workspace_bytes = workspace_bytes;
-  take_fp8(p);
+  take_fp8(p, arm);
   return conv_gemm(p, S(stream));
 }
 

@@ -47,16 +47,9 @@ namespace sdeo {
 // a weight-tile row is 64 bytes per K-step instead of 128, one DMA pass of the 256 loading threads covers 64 rows, and the
 // MFMA waves widen each 8-byte fragment to fp16 in registers (v_cvt_scalef32_pk_f16_fp8, exact) right before its MFMAs.
 // The activations, the accumulation and the epilogue are those of the fp16 kernel; what changes is the bytes streamed.
-// PERSIST (wave-specialised, unsplit plans with more tiles than resident workgroups): gridDim.x workgroups walk the tile list with
-// stride gridDim.x.  The loader waves never stop at a tile boundary: while the MFMA waves run the epilogue of tile t the ring already
-// receives the first PF K-steps of tile t + 1, so the DMA latency in front of a tile (~1.4 us) and the
-// epilogue overlap instead of adding up.  K-steps are numbered through all tiles of the workgroup (ring slot = step % STAGES, one
-// barrier per step on both sides as before) plus ONE barrier per tile in front of the epilogue, after which the slot of the tile's
-// last step -- the only one the loaders do not refill before the next tile's first barrier -- is the waves' epilogue scratch.
-template <int BM, int BN, int STAGES, bool UPS, bool WS, bool W8 = false, bool PERSIST = false>
+template <int BM, int BN, int STAGES, bool UPS, bool WS, bool W8 = false>
 __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2 pp) {
   const KP& p = pp.k[blockIdx.y];
-  static_assert(!PERSIST || WS, "the persistent tile loop is built on the loader / MFMA role split");
   constexpr int BK = 64, RPP = 32;
   constexpr int WRPP = W8 ? 64 : 32;                           // weight rows per DMA pass
   constexpr int XP = BM / RPP, WP = (BN + WRPP - 1) / WRPP, L = XP + WP;     // DMA instructions per loading thread per stage
@@ -202,38 +195,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
     });
   };
 
-  // persistent mode: this workgroup's tiles are blockIdx.x + j * gridDim.x; K-steps are numbered through all of them
-  const int my_tiles = PERSIST ? (p.tiles_m * p.tiles_n - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 1;
-  if constexpr (PERSIST) {
-    if (!do_mma) {                         // ---- loader waves, all tiles
-      const int total = my_tiles * nk;
-      int gi = 0, gk = 0, tj = 0;          // next global step to issue, its K-step inside its tile, tiles set up so far
-      auto issue_next = [&]() {
-        if (gk == 0 && tj > 0) { set_tile(blockIdx.x + tj * gridDim.x); loader_setup(); }
-        if (gk == 0) ++tj;
-        issue(gi % STAGES);
-        ++gi;
-        if (++gk == nk) gk = 0;
-      };
-#pragma unroll
-      for (int s = 0; s < PF; ++s)
-        if (gi < total) issue_next();
-      int kk = 0;
-      for (int g = 0; g < total; ++g) {
-        const int ahead = min(PF - 1, total - 1 - g);
-        static_for<PF>([&](auto A) {
-          if (ahead == A.value) wait_vmcnt<A.value * L>();
-        });
-        __builtin_amdgcn_s_barrier();
-        if (gi < total) issue_next();
-        if (++kk == nk) {
-          kk = 0;
-          __builtin_amdgcn_s_barrier();      // the MFMA waves' pre-epilogue barrier of this tile
-        }
-      }
-      return;
-    }
-  } else if constexpr (WS) {
+  if constexpr (WS) {
     if (!do_mma) {                         // ---- loader waves
       if (nk > 0) {
 #pragma unroll
@@ -251,9 +213,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
   }
 
   const int frow = lane & 15, fq = lane >> 4;
-  for (int tj = 0; tj < my_tiles; ++tj) {        // one pass unless PERSIST
-  if (PERSIST && tj > 0) set_tile(blockIdx.x + tj * gridDim.x);
-  const int g0 = PERSIST ? tj * nk : 0;          // global number of this tile's first K-step
+  constexpr int g0 = 0;
   f32x4 acc[NI][MI];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
@@ -263,8 +223,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
   // LayerNorm folded into this GEMM: (rstd, rstd * mean) of the tile's rows from the producer's per-strip partials, summed by
   // the MFMA waves of column 0 while the first K-step is in flight (they would wait on the first barrier otherwise) and parked
   // in LDS behind the ring; the epilogue reads two floats per row instead of re-summing up to N/32 partials per lane.
-  // (PERSIST: two copies by tile parity -- a wave may write the next tile's scalars while another still reads this tile's)
-  float2* lnsm = reinterpret_cast<float2*>(smem + STAGES * STAGE) + (PERSIST ? (tj & 1) * BM : 0);
+  float2* lnsm = reinterpret_cast<float2*>(smem + STAGES * STAGE);
   const bool ln_lds = p.ln_stats != nullptr && p.splitk == 1;
   if (ln_lds && wn == 0) {
     for (int rr = lane; rr < TM; rr += 64) {
@@ -437,18 +396,24 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
   __builtin_amdgcn_s_barrier();
   stamp(p, 3);
   if (dbg_on(p, 32)) return;
-  static_assert(4 * epilogue_scratch_bytes(TN) <= (PERSIST ? 1 : STAGES) * STAGE, "epilogue scratch");
-  // PERSIST: the scratch is the slot of the tile's LAST K-step (the other slots already receive the next tile)
-  constexpr int SCR = ((PERSIST ? 1 : STAGES) * STAGE / 4) & ~15;        // LDS each wave may use as epilogue scratch
+  static_assert(4 * epilogue_scratch_bytes(TN) <= STAGES * STAGE, "epilogue scratch");
+  constexpr int SCR = (STAGES * STAGE / 4) & ~15;        // LDS each wave may use as epilogue scratch
   constexpr int NBLK = epilogue_blocks(TN, MI, SCR);
-  char* scratch = smem + (PERSIST ? ((g0 + nk - 1) % STAGES) * STAGE : 0) + wave * SCR;
+  char* scratch = smem + wave * SCR;
   epilogue<NI, MI, TM, TN, NBLK>(pe, acc, m0, n0, wm, wn, frow, fq, z, bpre, use_bpre, scratch, ln_lds ? lnsm + wm * TM : nullptr);
+  if (pe.gn_out) {                         // GroupNorm partials of this tile (loader waves, if any, are gone: the barrier counts the rest)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 0) {                         // waves 2 wn and 2 wn + 1 share strip wn
+      const int bimg = m0 / pe.HoWo;
+      gn_partials_finish<TN, 2>(pe, smem + 2 * wn * SCR, SCR, lane, bimg, (m0 - bimg * pe.HoWo) / BM, n0 + wn * TN);
+    }
+  }
   if (dbg_on(p, 64)) {
     stamp(p, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(p, 5);
   }
-  }   // tile loop
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -825,6 +790,20 @@ int conv_gemm_stats_strips(const ConvGemm& p) {
 
 bool conv_gemm_plan_is_halo(const ConvGemm& p) { return kTiles[make_plan(p).tile].kind == TK_HALO; }
 
+// GroupNorm partials from the epilogue (KP::gn_out): entries per image the plan of p writes for groups of `cpg` channels, or 0 when it
+// cannot (split-K, a strip that cuts a group, a tile that straddles two images, the register-staged fallback kernel, an epilogue
+// that is not the LDS-transposed one)
+int conv_gemm_gn_slots(const ConvGemm& p, int cpg) {
+  if (cpg <= 0 || p.N % cpg || p.act == 3 || p.y32 || !p.y || p.bias_per_row || p.stats_out) return 0;
+  const Plan pl = make_plan(p);
+  const TileCfg& c = kTiles[pl.tile];
+  if (pl.splitk != 1 || c.kind == TK_GENERIC || plan_tn(pl) % cpg) return 0;
+  if (p.N % 8 || p.ldy % 8 || (reinterpret_cast<uintptr_t>(p.y) & 15) || (p.res && (p.ldres % 8 || (reinterpret_cast<uintptr_t>(p.res) & 15)))) return 0;
+  if (c.kind == TK_HALO) { const HaloCfg& h = kHaloCfgs[c.stages]; return (p.Hi / h.ph) * (p.Wi / h.pw); }
+  const int hw = p.Ho * p.Wo;
+  return hw % c.bm == 0 ? hw / c.bm : 0;
+}
+
 size_t conv_gemm_workspace_bytes(const ConvGemm& p) {
   const Plan pl = make_plan(p);
   return pl.splitk > 1 ? (size_t)pl.splitk * p.M * p.N * sizeof(float) : 0;
@@ -859,47 +838,11 @@ static int launch_dma_w8(const KP2& kp, int count, int tiles, hipStream_t stream
   return launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, true, true>, smem, &done, kp, count, tiles, stream, 512);
 }
 
-// persistent tile loop (see conv_gemm_dma_kernel).  OFF by default: measured on MI355X (tools/gemm_tiles.py, tools/gpu_session_q.sh)
-// it is worth 5 % on the ff.net.0.proj GEMMs and nothing on the step (7.05 vs 7.03 ms) -- these launches are bound by L2 -> LDS
-// operand traffic (~9 TB/s chip-wide), not by the per-tile prologue it hides.  SDEO_GEMM_PERSIST=1 or
-// conv_gemm_set_persist(1) turns it on (tests, A/B).
-static int g_persist = -1;
-void conv_gemm_set_persist(int on) { g_persist = on ? 1 : 0; }
-static bool use_persist() {
-#ifdef SDEO_DEBUG_KERNELS
-  return false;
-#else
-  if (g_persist < 0) { const char* e = getenv("SDEO_GEMM_PERSIST"); g_persist = e ? (atoi(e) != 0) : 0; }
-  return g_persist != 0;
-#endif
-}
-
-template <typename K>
-static int launch_persist(K kernel, int smem, bool* attr_done, const KP2& kp, int count, int wgs, hipStream_t stream) {
-  if (!*attr_done) {
-    SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    *attr_done = true;
-  }
-  hipLaunchKernelGGL(kernel, dim3(wgs, count, 1), dim3(512), smem, stream, kp);
-  SDEO_HIP(hipGetLastError());
-  return 0;
-}
-
 template <int BM, int BN, int ST>
 static int launch_dma(int ups, const KP2& kp, int count, int tiles, hipStream_t stream) {
-  static bool done[6] = {false, false, false, false, false, false};
+  static bool done[4] = {false, false, false, false};
   constexpr int smem = ST * (BM + BN) * 128 + BM * 8;      // ring + the LayerNorm row scalars (conv_gemm_dma_kernel: lnsm)
   if (use_ws()) {
-    // more tiles than resident workgroups and an unsplit plan: the workgroups walk the tile list (loaders prefetch across tiles)
-    constexpr bool can_persist = 4 * epilogue_scratch_bytes(BN / 2) <= (BM + BN) * 128;
-    if constexpr (can_persist) {
-      constexpr int psmem = smem + BM * 8;
-      constexpr int occ = (160 * 1024) / psmem >= 2 ? 2 : 1;
-      const int wgs = kNumCU * occ;
-      if (use_persist() && kp.k[0].splitk == 1 && tiles > wgs)
-        return ups ? launch_persist(&conv_gemm_dma_kernel<BM, BN, ST, true, true, false, true>, psmem, &done[5], kp, count, wgs, stream)
-                   : launch_persist(&conv_gemm_dma_kernel<BM, BN, ST, false, true, false, true>, psmem, &done[4], kp, count, wgs, stream);
-    }
     return ups ? launch_k(&conv_gemm_dma_kernel<BM, BN, ST, true, true>, smem, &done[3], kp, count, tiles, stream, 512)
                : launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, true>, smem, &done[2], kp, count, tiles, stream, 512);
   }
@@ -967,6 +910,12 @@ static int prepare(const ConvGemm& p, Plan& pl, KP& kp) {
                "conv_gemm: row statistics need an unsplit fp16 plan (strips %d, stats_ld %d)", strips, p.stats_ld);
     kp.stats_out = p.stats_out; kp.stats_ld = p.stats_ld;
   }
+  if (p.gn_out) {
+    const int slots = conv_gemm_gn_slots(p, p.gn_cpg);
+    SDEO_CHECK(slots > 0 && slots == p.gn_slots && p.gn_groups * p.gn_cpg == p.N,
+               "conv_gemm: GroupNorm partials need an unsplit fp16 plan whose strips cover whole groups (slots %d, expected %d)", slots, p.gn_slots);
+    kp.gn_out = p.gn_out; kp.gn_cpg = p.gn_cpg; kp.gn_slots = p.gn_slots; kp.gn_groups = p.gn_groups;
+  }
   kp.nk = pl.nk; kp.splitk = pl.splitk; kp.nk_per_split = cdiv(pl.nk, pl.splitk);
   kp.tiles_m = pl.tiles_m; kp.tiles_n = pl.tiles_n;
   {
@@ -984,6 +933,7 @@ static int prepare(const ConvGemm& p, Plan& pl, KP& kp) {
     kp.coalesce = epi && p.y && !p.y32 && pl.splitk == 1 && !p.bias_per_row && p.N % (p.act == 3 ? 16 : 8) == 0 && p.ldy % 8 == 0 &&
                   (reinterpret_cast<uintptr_t>(p.y) & 15) == 0 &&
                   (!p.res || (p.ldres % 8 == 0 && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0));
+    SDEO_CHECK(!p.gn_out || kp.coalesce, "conv_gemm: GroupNorm partials need the LDS-transposed epilogue");
   }
   if (pl.splitk > 1) {
     const size_t need = (size_t)pl.splitk * p.M * p.N * sizeof(float);

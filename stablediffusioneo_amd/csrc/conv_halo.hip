@@ -251,6 +251,11 @@ __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP2 
   constexpr int SCR = ((2 * XBYTES + WST * WBYTES) / NMW) & ~15;           // LDS each MFMA wave may use as epilogue scratch
   constexpr int NBLK = epilogue_blocks(BN, MI, SCR);
   epilogue_rows<NI, MI, BN, NBLK>(pe, acc, mrow, n0, fq, z, bpre, use_bpre, smem + wave * SCR);
+  if (pe.gn_out) {                         // GroupNorm partials of this patch: the loader waves are gone, the barrier counts the rest
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave == 0) gn_partials_finish<BN, NMW>(pe, smem, SCR, lane, b, trem, n0);
+  }
   if (dbg_on(p, 64)) {
     stamp(p, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -44,6 +44,12 @@ struct KP {
   // ---- producer side: per-row partial (sum, sumsq) of the values this launch stores, one partial per TN-wide strip
   float* stats_out;        // [M][stats_ld][2]; null = off
   int stats_ld;
+  // ---- producer side, GroupNorm (`util.py:217-219`): per-(image, M tile of the image, group) partial (sum, sumsq) of the values this
+  //      launch stores, so that the GroupNorm that consumes y needs no statistics pass.  Every (image, tile, group) entry is written
+  //      by exactly one workgroup (host-checked: strips cover whole groups, tiles do not straddle images, unsplit fp16 plan);
+  //      the consumer sums the gn_slots entries of a group in a fixed order (deterministic, no atomics).
+  float* gn_out;           // [B][gn_slots][gn_groups][2]; null = off
+  int gn_cpg, gn_slots, gn_groups;
 };
 
 // What a kernel receives: one problem, or two independent problems of the SAME plan (grid, tile, split-K, template instance)
@@ -97,7 +103,8 @@ __device__ __forceinline__ int swz_chunk(int row, int chunk) {
 // wave transposes each 16-row block of fp32 results through LDS so that every lane then moves 8 consecutive channels:
 // 16-byte residual loads and 16-byte stores in runs of TN*2 contiguous bytes per row, instead of 8-byte pieces in 32-byte
 // runs (measured: the 8-byte epilogue took ~4 us of a 24 us conv).  Same arithmetic, same single rounding.
-constexpr int epilogue_scratch_bytes(int tn) { return 16 * (tn * 4 + 16) + 16 * tn; }   // + [16 rows][tn / 8] float2 row-statistics partials
+constexpr int epilogue_scratch_bytes(int tn) { return 16 * (tn * 4 + 16) + 32 * tn; }   // + [16 rows][tn / 8] float2 row-statistics partials
+                                                                                        //   or [16 rows][tn] fp16 copy of the stored block (GroupNorm partials)
 
 // The epilogue reads ~25 scalar parameters.  Left to the compiler they are loaded from the kernel-argument segment where first
 // used, one s_load + s_waitcnt lgkmcnt(0) after the other (the loads are invariant, so it prefers re-loading to keeping SGPRs
@@ -121,12 +128,13 @@ __device__ __forceinline__ void pin_epilogue_scalars(KP& q) {
   // epilogue's LDS traffic)
 #define SDEO_PIN_PTR(f) q.f = (decltype(q.f))(__attribute__((address_space(1))) std::remove_pointer_t<decltype(q.f)>*)pin_u64((unsigned long long)q.f);
   SDEO_PIN_PTR(y) SDEO_PIN_PTR(y32) SDEO_PIN_PTR(bias) SDEO_PIN_PTR(bias2) SDEO_PIN_PTR(res) SDEO_PIN_PTR(ws)
-  SDEO_PIN_PTR(wscale) SDEO_PIN_PTR(stats_out) SDEO_PIN_PTR(ln_stats) SDEO_PIN_PTR(ln_s)
+  SDEO_PIN_PTR(wscale) SDEO_PIN_PTR(stats_out) SDEO_PIN_PTR(ln_stats) SDEO_PIN_PTR(ln_s) SDEO_PIN_PTR(gn_out)
 #undef SDEO_PIN_PTR
   q.M = pin_i32(q.M); q.N = pin_i32(q.N); q.HoWo = pin_i32(q.HoWo); q.ldy = pin_i32(q.ldy); q.ldres = pin_i32(q.ldres);
   q.ld_bias2 = pin_i32(q.ld_bias2); q.act = pin_i32(q.act); q.bias_per_row = pin_i32(q.bias_per_row); q.scale = pin_f32(q.scale);
   q.splitk = pin_i32(q.splitk); q.coalesce = pin_i32(q.coalesce); q.stats_ld = pin_i32(q.stats_ld); q.ln_strips = pin_i32(q.ln_strips);
   q.ln_ld = pin_i32(q.ln_ld); q.ln_invc = pin_f32(q.ln_invc); q.ln_eps = pin_f32(q.ln_eps);
+  q.gn_cpg = pin_i32(q.gn_cpg); q.gn_slots = pin_i32(q.gn_slots); q.gn_groups = pin_i32(q.gn_groups);
 }
 
 // blocks staged per round: the largest divisor of MI whose scratch fits `budget` bytes per wave and whose residual registers
@@ -305,6 +313,12 @@ __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI],
       live[t] = id < 16 * G && nn[t] < p.N;
     }
     const int mode = (p.bias2 ? 3 : 0) + p.act;   // act is 0..2 here (3 = GEGLU never takes this path)
+    // GroupNorm partials (KP::gn_out): lane c (and c + 64 ...) sums column c of every stored block, read back from an fp16 copy of
+    // the block in LDS -- two registers per column instead of sixteen per (row, vector) slot
+    constexpr int GCH = (TN + 63) / 64;
+    float gsum[GCH], gsq[GCH];
+#pragma unroll
+    for (int c = 0; c < GCH; ++c) { gsum[c] = 0.f; gsq[c] = 0.f; }
     stamp(p, 8);
 #pragma unroll
     for (int j0 = 0; j0 < MI; j0 += NB) {
@@ -370,8 +384,26 @@ __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI],
 #pragma unroll
               for (int u = 0; u < 8; ++u) { const float f = (float)o[u]; ssum += f; ssq += f * f; }
             }
+            if (p.gn_out) *reinterpret_cast<f16x8*>(scratch + jb * BLOCKB + 16 * ROWB + (rr[t] * TN + (nn[t] - nb)) * 2) = o;
+          } else if (p.gn_out && t * 64 + lane < 16 * G) {     // rows / columns past the problem count as zeros
+            *reinterpret_cast<f16x8*>(scratch + jb * BLOCKB + 16 * ROWB + (rr[t] * TN + (nn[t] - nb)) * 2) = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
           }
           if (p.stats_out && t * 64 + lane < 16 * G) spart[t * 64 + lane] = make_float2(ssum, ssq);     // index = row * G + group
+        }
+      }
+      if (p.gn_out) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb) {
+          const f16* blk = reinterpret_cast<const f16*>(scratch + jb * BLOCKB + 16 * ROWB);
+#pragma unroll
+          for (int c = 0; c < GCH; ++c) {
+            const int col = c * 64 + lane;
+            if (col < TN) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) { const float f = (float)blk[r * TN + col]; gsum[c] += f; gsq[c] += f * f; }
+            }
+          }
         }
       }
       if (p.stats_out) {
@@ -391,6 +423,11 @@ __device__ __forceinline__ void epilogue_rows(const KP& p, f32x4 (&acc)[NI][MI],
       }
       if (j0 == 0) stamp(p, 11);
       __builtin_amdgcn_wave_barrier();        // the next round overwrites the scratch rows
+    }
+    if (p.gn_out) {      // this wave's per-column (sum, sumsq) at the start of its scratch: gn_partials_finish combines the waves
+#pragma unroll
+      for (int c = 0; c < GCH; ++c)
+        if (c * 64 + lane < TN) reinterpret_cast<float2*>(scratch)[c * 64 + lane] = make_float2(gsum[c], gsq[c]);
     }
     stamp(p, 12);
     return;
@@ -485,6 +522,33 @@ __device__ __forceinline__ void epilogue(const KP& p, f32x4 (&acc)[NI][MI], int 
     mrow[j] = m < p.M ? m : -1;
   }
   epilogue_rows<NI, MI, TN, NB>(p, acc, mrow, n0 + wn * TN, fq, z, bpre, use_bpre, scratch, lnrow);
+}
+
+// GroupNorm partials, second half (KP::gn_out).  After epilogue_rows every wave's scratch starts with the per-column (sum, sumsq)
+// of the rows it stored.  Called by ONE wave per TN-wide strip after a workgroup barrier: sums the NW waves that share the strip
+// (scratch bases `base + w * stride`), then the gn_cpg columns of each group, and writes entry (image b, tile slot, group).
+template <int TN, int NW>
+__device__ __forceinline__ void gn_partials_finish(const KP& p, char* base, int stride, int lane, int b, int slot, int nb) {
+  constexpr int GCH = (TN + 63) / 64;
+  float2* tot = reinterpret_cast<float2*>(base) + TN;          // behind wave 0's own column sums
+#pragma unroll
+  for (int c = 0; c < GCH; ++c) {
+    const int col = c * 64 + lane;
+    if (col < TN) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { const float2 v = reinterpret_cast<const float2*>(base + w * stride)[col]; s += v.x; q += v.y; }
+      tot[col] = make_float2(s, q);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int cpg = p.gn_cpg;
+  const int g = (nb / cpg) + lane;                             // strips start on a group boundary (host-checked)
+  if (lane * cpg < TN && nb + lane * cpg < p.N) {
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < cpg; ++k) { const float2 v = tot[lane * cpg + k]; s += v.x; q += v.y; }
+    reinterpret_cast<float2*>(p.gn_out)[((size_t)b * p.gn_slots + slot) * p.gn_groups + g] = make_float2(s, q);
+  }
 }
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (observed, speed only), so give each

@@ -47,8 +47,14 @@ struct ConvGemm {
   // emit per-row partial (sum, sumsq) of the stored fp16 values: stats_out[m][stats_ld][2], conv_gemm_stats_strips(p) valid
   float* stats_out = nullptr;
   int stats_ld = 0;
+  // emit GroupNorm partials of the stored fp16 values: gn_out[b][gn_slots][gn_groups][2] = (sum, sumsq) of the gn_cpg channels of a
+  // group over the rows of one M tile of image b; gn_slots must equal conv_gemm_gn_slots(p, gn_cpg) (> 0)
+  float* gn_out = nullptr;
+  int gn_cpg = 0, gn_slots = 0, gn_groups = 0;
 };
 int conv_gemm(const ConvGemm& p, hipStream_t stream);
+// M tiles per image of the plan chosen for p when its epilogue can emit GroupNorm partials for groups of cpg channels, else 0
+int conv_gemm_gn_slots(const ConvGemm& p, int cpg);
 // Pair launch: two independent problems of one shape and plan in ONE launch (blockIdx.y selects the problem; a split-K plan
 // needs distinct workspaces).  Falls back to two launches when the plans differ.  Results are those of two single launches.
 bool conv_gemm_can_pair(const ConvGemm& a, const ConvGemm& b);
@@ -65,7 +71,6 @@ int conv_gemm_plan_splitk(const ConvGemm& p);       // split-K factor of the pla
 // name of the kernel instantiation the launcher will pick (for profiles; matches the rocprof kernel name's template args)
 const char* conv_gemm_kernel_name(const ConvGemm& p);
 void conv_gemm_debug_force(int tile, int splitk);
-void conv_gemm_set_persist(int on);                // persistent tile loop of the wave-specialised kernel (off by default)
 void conv_gemm_debug_force_order(int order);       // -1 heuristic, 0 M-fastest, 1 N-fastest tile order
 // one-time on-device plan search for p's shape (p needs valid scratch pointers); workspace to reserve for it
 int conv_gemm_autotune(const ConvGemm& p, hipStream_t stream);
@@ -102,6 +107,11 @@ struct GnArgs {
   float eps;
   int with_silu;
   GnReduce red{};                  // with red.ws set, `x` is where the reduced tensor is WRITTEN (and normalised from LDS)
+  // statistics already exist: ext_partials[b][ext_nsc][groups][2] = (sum, sumsq) partials written by the epilogue of the conv / GEMM
+  // that produced x (ConvGemm::gn_out).  Then no statistics pass runs: ONE launch normalises (plus a small reduction launch when
+  // ext_nsc > 128, the VAE's large images: `partials` is its workspace, >= B * groups * 2 floats)
+  const float* ext_partials = nullptr;
+  int ext_nsc = 0;
 };
 // whether groupnorm_nhwc(a) runs as ONE launch with its slice in LDS (the only form that can take GnReduce)
 bool groupnorm_is_single_launch(const GnArgs& a);

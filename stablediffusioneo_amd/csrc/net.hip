@@ -182,6 +182,10 @@ struct T {           // fp16 activation view: rows x c, row stride ld; (n,h,w) w
   f16* p = nullptr;
   size_t off = (size_t)-1;   // arena offset when owned
   int n = 0, h = 0, w = 0, c = 0, ld = 0;
+  // GroupNorm partials of this tensor written by the epilogue of the conv / GEMM that produced it (ConvGemm::gn_out), 32 groups
+  float* gnp = nullptr;
+  size_t gnp_off = (size_t)-1;
+  int gn_slots = 0;
   int rows() const { return n * h * w; }
 };
 
@@ -516,6 +520,7 @@ struct ConvOpts {                     // conv / gemm options
   RowStats* stats = nullptr;     // producer: emit per-row (sum, sumsq) partials of the stored values into this buffer
   const RowStats* ln = nullptr;  // consumer: LayerNorm folded into this GEMM, statistics of x from *ln, row sums ln_s
   const float* ln_s = nullptr;
+  bool gn_next = false;          // the output feeds a GroupNorm(32): let the epilogue emit its partial statistics when the plan can
 };
 
 struct Builder {
@@ -540,6 +545,21 @@ struct Builder {
   void release(T& t) {
     if (t.off != (size_t)-1) arena->release(t.off);
     t.off = (size_t)-1;
+    if (t.gnp_off != (size_t)-1) arena->release(t.gnp_off);
+    t.gnp_off = (size_t)-1;
+    t.gnp = nullptr;
+  }
+  // producer side of the GroupNorm fusion: when the plan of p can, give it a partials buffer and record it on the output tensor
+  static bool gn_from_producer() { static const bool on = [] { const char* v = getenv("SDEO_GN_PRODUCER_STATS"); return !v || atoi(v) != 0; }(); return on; }
+  void want_gn_partials(ConvGemm& p, T& y, int images) {
+    const int G = 32;
+    if (!gn_from_producer() || p.N % G) return;
+    const int cpg = p.N / G, slots = conv_gemm_gn_slots(p, cpg);
+    if (slots <= 0) return;
+    y.gnp_off = arena->alloc((size_t)images * slots * G * 2 * sizeof(float));
+    y.gnp = reinterpret_cast<float*>(base + y.gnp_off);
+    y.gn_slots = slots;
+    p.gn_out = y.gnp; p.gn_cpg = cpg; p.gn_slots = slots; p.gn_groups = G;
   }
   void push(Op op, const char* key = "elementwise", double flops = 0, double bytes = 0, const std::string& tag = std::string(),
             std::shared_ptr<PairDesc> pd = nullptr) {
@@ -645,6 +665,7 @@ struct Builder {
     p.B = x.n; p.Hi = x.h; p.Wi = x.w; p.Cin = x.c; p.Ho = ho; p.Wo = wo; p.R = p.S = k; p.stride = stride; p.pad = pad; p.ups = ups;
     p.M = x.n * ho * wo; p.N = cs; p.K = k * k * x.c;
     p.ldx = x.ld; p.ldw = p.K; p.ldy = y.ld; p.act = o.act;
+    if (o.gn_next && !o.out && !o.scale_host && cs == y.c) want_gn_partials(p, y, x.n);
     launch_conv(p, o.scale_host, o.stats);
     T r = y;
     if (o.out) r.off = (size_t)-1;
@@ -693,6 +714,16 @@ struct Builder {
     auto pd = std::make_shared<PairDesc>();
     pd->kind = PairDesc::GN; pd->sel = sel;
     pd->gn = GnArgs{yp, xp, g, b, nullptr, ldy, ldx, B, HW, C, 32, eps, silu_};
+    if (x.gnp && !groupnorm_is_single_launch(pd->gn)) {
+      // the statistics came out of the producer's epilogue: one launch (normalise) instead of two
+      GnArgs ga = pd->gn;
+      ga.ext_partials = x.gnp; ga.ext_nsc = x.gn_slots;
+      max_gn = std::max(max_gn, (size_t)B * 32 * 2 * sizeof(float));
+      push([=](hipStream_t s) mutable { ga.partials = sel ? eng->gn_ws2 : eng->gn_ws; return groupnorm_nhwc(ga, s); }, "groupnorm", 0,
+           2.0 * 2.0 * B * HW * C, "C" + std::to_string(C) + " HW" + std::to_string(HW) + " apply");
+      if (out) y.off = (size_t)-1;
+      return y;
+    }
     push([=](hipStream_t s) { return groupnorm_nhwc(yp, ldy, xp, ldx, g, b, B, HW, C, 32, eps, silu_, sel ? eng->gn_ws2 : eng->gn_ws, s); }, "groupnorm", 0,
          3.0 * 2.0 * B * HW * C, "C" + std::to_string(C) + " HW" + std::to_string(HW), pd);
     if (out) y.off = (size_t)-1;
@@ -728,6 +759,7 @@ static T build_res(Builder& b, const std::string& ns, const Blk& blk, const T& x
   Builder::CO o1;
   o1.bias2 = emb_all + b.e->emb_row.at(p);
   o1.ld_bias2 = emb_ld;
+  o1.gn_next = true;
   T h1 = b.conv(t1, p + ".in_layers.2", blk.cout, 3, 1, 0, o1);
   b.release(t1);
   T t2 = b.gn(h1, p + ".out_layers.0", 1e-5f, 1);
@@ -741,6 +773,7 @@ static T build_res(Builder& b, const std::string& ns, const Blk& blk, const T& x
   Builder::CO o2;
   o2.res = res;
   o2.out = out;
+  o2.gn_next = true;
   T y = b.conv(t2, p + ".out_layers.3", blk.cout, 3, 1, 0, o2);
   b.release(t2);
   if (blk.cin != blk.cout) b.release(skip);
@@ -794,7 +827,7 @@ static T build_attn(Builder& b, const std::string& ns, const Blk& blk, const T& 
   b.release(gg);
   b.release(tok2);
   b.release_stats();
-  Builder::CO ro; ro.res = &x; ro.out = out;
+  Builder::CO ro; ro.res = &x; ro.out = out; ro.gn_next = true;
   T y = b.conv(tok3, p + ".proj_out", C, 1, 1, 0, ro);
   b.release(tok3);
   return y;
@@ -1043,11 +1076,11 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
       const T* out = (i + 1 == blocks.size()) ? final_out : nullptr;
       T y;
       switch (blk.kind) {
-        case B_CONV_IN: { Builder::CO o; o.out = out; y = b.conv(x, ns + blk.name, blk.cout, 3, 1, 0, o); break; }
+        case B_CONV_IN: { Builder::CO o; o.out = out; o.gn_next = true; y = b.conv(x, ns + blk.name, blk.cout, 3, 1, 0, o); break; }
         case B_RES: y = build_res(b, ns, blk, x, emb_all, emb_ld, out); break;
         case B_ATTN: y = build_attn(b, ns, blk, x, bt.kv[net].at(ns + blk.name), out); break;
-        case B_DOWN: { Builder::CO o; o.out = out; y = b.conv(x, ns + blk.name + ".op", blk.cout, 3, 2, 0, o); break; }
-        case B_UP: { Builder::CO o; o.out = out; y = b.conv(x, ns + blk.name + ".conv", blk.cout, 3, 1, 1, o); break; }
+        case B_DOWN: { Builder::CO o; o.out = out; o.gn_next = true; y = b.conv(x, ns + blk.name + ".op", blk.cout, 3, 2, 0, o); break; }
+        case B_UP: { Builder::CO o; o.out = out; o.gn_next = true; y = b.conv(x, ns + blk.name + ".conv", blk.cout, 3, 1, 1, o); break; }
       }
       if (release_in || i > 0) b.release(x);
       x = y;
@@ -1071,7 +1104,7 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
       T y;
       if (i == 0) {
         // input_blocks.0 conv, then h += guided_hint (residual epilogue)
-        Builder::CO o; o.res = &bt.hint_feat;
+        Builder::CO o; o.res = &bt.hint_feat; o.gn_next = true;
         y = b.conv(hcur, ns + e->cplan.in[0][0].name, c.model_channels, 3, 1, 0, o);
         b.release(hcur);
       } else {
@@ -1193,17 +1226,18 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
     b.release(z);
     int bin = 0;
     auto levels = vae_levels(c, &bin);
-    T hcur = b.conv(z2, d + ".conv_in", bin, 3, 1, 0);
+    Builder::CO gnx; gnx.gn_next = true;       // every conv of the decoder below feeds a GroupNorm
+    T hcur = b.conv(z2, d + ".conv_in", bin, 3, 1, 0, gnx);
     b.release(z2);
     auto vres = [&](const std::string& p, const T& x, int cin, int cout) {
       T t1 = b.gn(x, p + ".norm1", 1e-6f, 1);
-      T h1 = b.conv(t1, p + ".conv1", cout, 3, 1, 0);
+      T h1 = b.conv(t1, p + ".conv1", cout, 3, 1, 0, gnx);
       b.release(t1);
       T t2 = b.gn(h1, p + ".norm2", 1e-6f, 1);
       b.release(h1);
       T sk; const T* res = &x;
       if (cin != cout) { sk = b.conv(x, p + ".nin_shortcut", cout, 1, 1, 0); res = &sk; }
-      Builder::CO o; o.res = res;
+      Builder::CO o; o.res = res; o.gn_next = true;
       T y = b.conv(t2, p + ".conv2", cout, 3, 1, 0, o);
       b.release(t2);
       if (cin != cout) b.release(sk);
@@ -1248,7 +1282,7 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
         b.release(pr);
         b.release(vt);
       }
-      Builder::CO ro; ro.res = &hcur;
+      Builder::CO ro; ro.res = &hcur; ro.gn_next = true;
       T yo = b.conv(o, p + ".proj_out", bin, 1, 1, 0, ro);
       b.release(o);
       b.release(hcur);
@@ -1266,7 +1300,7 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
         last = L.blocks[j].second;
       }
       if (L.up) {
-        y = b.conv(hcur, d + ".up." + std::to_string(L.level) + ".upsample.conv", last, 3, 1, 1);
+        y = b.conv(hcur, d + ".up." + std::to_string(L.level) + ".upsample.conv", last, 3, 1, 1, gnx);
         b.release(hcur);
         hcur = y;
       }

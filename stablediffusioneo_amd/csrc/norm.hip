@@ -252,6 +252,22 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnPair gp, int Bper
   }
 }
 
+// producer-side partials with more entries per group than the apply kernel should re-sum in every workgroup: one block per
+// (image, group) folds them to a single entry, fixed order (per-thread strided sums, then a fixed tree)
+__global__ __launch_bounds__(256) void gn_fold_partials_kernel(float2* __restrict__ out, const float2* __restrict__ in, int nsc, int groups) {
+  __shared__ float2 red[256];
+  const int b = blockIdx.x / groups, g = blockIdx.x - b * groups, tid = threadIdx.x;
+  float s = 0.f, q = 0.f;
+  for (int c = tid; c < nsc; c += 256) { const float2 v = in[((size_t)b * nsc + c) * groups + g]; s += v.x; q += v.y; }
+  red[tid] = make_float2(s, q);
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (tid < off) { red[tid].x += red[tid + off].x; red[tid].y += red[tid + off].y; }
+    __syncthreads();
+  }
+  if (tid == 0) out[(size_t)b * groups + g] = red[0];
+}
+
 // ------------------------------------------------------------------------------------------------
 // Single-launch GroupNorm for tensors whose per-(image, group set) slice fits in one workgroup's LDS.
 // Every kernel on this chip costs ~4 us of launch + dependent round trips whatever its size (DESIGN.md
@@ -470,7 +486,7 @@ static int launch_gn_fused(const GnPair& gp, int count, int B, int HW, int C, in
 }
 
 static int gn_check(const GnArgs& a) {
-  SDEO_CHECK(a.y && a.x && a.gamma && a.beta && a.partials, "groupnorm: null operand");
+  SDEO_CHECK(a.y && a.x && a.gamma && a.beta && (a.partials || (a.ext_partials && a.ext_nsc <= 128)), "groupnorm: null operand");
   SDEO_CHECK(a.B > 0 && a.HW > 0 && a.C > 0, "groupnorm: empty tensor");
   SDEO_CHECK(a.groups > 0 && a.groups <= 64 && a.C % a.groups == 0, "groupnorm: C=%d not divisible into %d groups", a.C, a.groups);
   SDEO_CHECK(a.C % 8 == 0 && a.ldx % 8 == 0 && a.ldy % 8 == 0, "groupnorm: C=%d ldx=%d ldy=%d must be multiples of 8", a.C, a.ldx, a.ldy);
@@ -505,6 +521,28 @@ static int gn_dispatch(const GnArgs& a, const GnPair& gp, int count, hipStream_t
   const int B = a.B, HW = a.HW, C = a.C, groups = a.groups, with_silu = a.with_silu;
   const float eps = a.eps;
   const int cpg = C / groups;
+  if (a.ext_partials) {
+    // statistics came out of the producer's epilogue: normalise only
+    SDEO_CHECK(count == 1 && !a.red.ws && a.ext_nsc >= 1, "groupnorm: producer partials go with a single, plain problem");
+    const int nvb = gn_vec_per_block(C, groups);
+    SDEO_CHECK(nvb > 0, "groupnorm: unsupported channel split C=%d groups=%d", C, groups);
+    const int parts = (C / 8) / nvb, P = 256 / nvb;
+    int chunks = cdiv(HW, 4 * P);
+    if (chunks > 2048) chunks = 2048;
+    const int ppc = cdiv(HW, chunks);
+    GnPair g2 = gp;
+    int nsc = a.ext_nsc;
+    if (nsc > 128) {
+      hipLaunchKernelGGL(gn_fold_partials_kernel, dim3(B * groups), dim3(256), 0, stream, reinterpret_cast<float2*>(a.partials),
+                         reinterpret_cast<const float2*>(a.ext_partials), nsc, groups);
+      nsc = 1;
+    } else {
+      for (int i = 0; i < SDEO_PAIR_SLOTS; ++i) g2.k[i].partials = const_cast<float*>(a.ext_partials);
+    }
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks, parts, B), dim3(256), 0, stream, g2, B, HW, C, cpg, nvb, chunks, groups, eps, with_silu, ppc, nsc);
+    SDEO_HIP(hipGetLastError());
+    return 0;
+  }
   {
     const int nt = gn_fused_threads(a);
     const int nvw = gn_fused_vecs(C, cpg);

@@ -11,9 +11,6 @@ extern "C" {
 
 /* force tile config / split-K of the following conv/GEMM launches (-1, 0 = plan table / heuristic) */
 void sdeo_debug_force_gemm_plan(int tile, int splitk);
-/* persistent tile loop of the wave-specialised implicit-GEMM kernel (unsplit plans with more tiles than resident workgroups);
- * off by default (measured neutral on the step), same results either way */
-void sdeo_debug_set_gemm_persist(int on);
 void sdeo_debug_force_gemm_order(int order); /* -1 heuristic, 0 M-fastest, 1 N-fastest tile order within an XCD */
 /* name of the kernel instantiation sdeo_conv2d_nhwc_f16 would launch for this problem (plan table / forced plan / heuristic) */
 const char* sdeo_debug_conv2d_kernel_name(int n, int h, int w, int cin, int cout, int ksize, int stride, int upsample2x);
@@ -36,6 +33,12 @@ int sdeo_debug_gemm_stats_f16(void* y, int ldy, const void* x, int ldx, const vo
 int sdeo_debug_gemm_ln_f16(void* y, int ldy, const void* x, int ldx, const void* w_folded, int ldw, const float* ln_s,
                            const float* bias_folded, const float* stats, int stats_ld, int strips, int ln_c, int m, int n, int k, int act, float eps, void* workspace, size_t workspace_bytes, void* stream);
 int sdeo_debug_row_stats_f16(float* stats, int stats_ld, const void* x, int ldx, int rows, int c, void* stream);
+/* [conv whose epilogue emits the GroupNorm partials of its output] -> [normalise-only GroupNorm]: the pair csrc/net.hip builds for
+ * every conv that feeds a GroupNorm.  *slots = partial entries per image (0: this shape's plan cannot emit them, nothing ran);
+ * partials >= n * slots * groups * 2 floats (+ n * groups * 2 when slots > 128) */
+int sdeo_debug_conv2d_gn_f16(void* ynorm, void* y, const void* x, const void* w_krsc, const float* bias, const void* res, int n, int h,
+                             int w, int cin, int cout, int ksize, int stride, int upsample2x, const float* gamma, const float* beta,
+                             int groups, float eps, int with_silu, float* partials, size_t partial_floats, int* slots, void* stream);
 
 /* fp8 weight pack at op level (tests): quantise [rows][cols] fp16 in place to its dequantised values, codes -> q, scales -> scale;
  * sdeo_debug_next_weights_fp8 makes the NEXT sdeo_gemm_f16 / sdeo_conv2d_nhwc_f16 call of this thread stream these codes

@@ -88,6 +88,31 @@ def conv2d_nhwc(x, w_krsc, bias=None, bias2=None, res=None, stride=1, upsample2x
     return y
 
 
+def conv2d_gn(x, w_krsc, gamma, beta, bias=None, res=None, stride=1, upsample2x=False, groups=32, eps=1e-5, swish=False):
+    """[conv2d whose epilogue emits the GroupNorm partials of its output] -> [normalise-only GroupNorm]: returns (y, GroupNorm(y), slots)
+    or None when the plan of this shape cannot emit partials (split-K, strips cutting a group, ...)."""
+    lib = _lib.load()
+    _need_cuda(x, w_krsc, gamma, beta)
+    n, h, w, cin = x.shape
+    cout, k, _, cin_w = w_krsc.shape
+    assert cin == cin_w and x.is_contiguous() and w_krsc.is_contiguous()
+    hv, wv = (2 * h, 2 * w) if upsample2x else (h, w)
+    pad = k // 2
+    ho = (hv + 2 * pad - k) // stride + 1
+    wo = (wv + 2 * pad - k) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float16, device=x.device)
+    yn = torch.empty_like(y)
+    pf = n * (ho * wo) * groups * 2 // 16 + n * groups * 2 + 1024           # tiles hold >= 32 rows: more than any plan needs
+    part = torch.zeros(pf, dtype=torch.float32, device=x.device)
+    slots = C.c_int(0)
+    check(lib.sdeo_debug_conv2d_gn_f16(ptr(yn), ptr(y), ptr(x), ptr(w_krsc), ptr(bias), ptr(res), _i(n), _i(h), _i(w), _i(cin), _i(cout),
+                                       _i(k), _i(stride), _i(int(upsample2x)), ptr(gamma), ptr(beta), _i(groups), _f(eps), _i(int(swish)),
+                                       ptr(part), C.c_size_t(pf), C.byref(slots), cur_stream()), "conv2d_gn")
+    if slots.value == 0:
+        return None
+    return y, yn, slots.value
+
+
 def gemm(x, w, bias=None, res=None, act=0, scale=1.0, out_f32=False, bias_per_row=False, w8=None):
     """y[m][n] = x[m][k] . w[n][k]^T (+bias)(+res); x, w fp16 row-major (may be strided views with unit inner stride).
     w8 = (codes, scales): stream the fp8 copy of w instead."""

@@ -164,38 +164,6 @@ def test_conv2d_every_dma_tile(ops, tile, sk):
         lib.sdeo_debug_force_gemm_plan(C.c_int(-1), C.c_int(0))
 
 
-PERSIST_TILES = [0, 1, 2, 6, 7, 10, 11, 12, 19, 21]     # tiles whose epilogue scratch fits one ring slot (BM <= 128): persistent tile loop
-
-
-@pytest.mark.parametrize("tile", PERSIST_TILES)
-def test_conv2d_persistent_tile_loop(ops, tile):
-    """More tiles than resident workgroups on an unsplit plan: the workgroups walk the tile list while the loader waves prefetch
-    across tile boundaries (conv_gemm_dma_kernel<..., PERSIST>).  Ragged M and N (the last tiles are partial), a 1x1 with a
-    residual, a 3x3, the folded upsample; every case has > 2 x 256 tiles for every tile shape in the list."""
-    import ctypes as C
-    from stablediffusioneo_amd import _lib
-    lib = _lib.load()
-    try:
-        lib.sdeo_debug_set_gemm_persist(C.c_int(1))            # off by default (measured neutral on the DDIM step)
-        lib.sdeo_debug_force_gemm_plan(C.c_int(tile), C.c_int(1))
-        for (n, cin, h, w, cout, k, ups) in [(1, 64, 125, 131, 328, 1, 0), (2, 64, 96, 100, 200, 3, 0), (1, 64, 70, 66, 264, 3, 1)]:
-            x = h16(randn((n, cin, h, w), 240 + cin))
-            wt = h16(randn((cout, cin, k, k), 241) * (1.0 / (cin * k * k)) ** 0.5)
-            bias = 0.1 * randn((cout,), 242)
-            xin = F.interpolate(x.float(), scale_factor=2, mode="nearest") if ups else x.float()
-            ref = F.conv2d(xin, wt.float(), bias, padding=k // 2)
-            res = None
-            if k == 1:
-                res = h16(randn(tuple(ref.shape), 243))
-                ref = ref + res.float()
-            y = ops.conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV), wt.permute(0, 2, 3, 1).contiguous().to(DEV), bias.to(DEV),
-                                res=None if res is None else res.permute(0, 2, 3, 1).contiguous().to(DEV), upsample2x=bool(ups))
-            assert_close(y.permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3, what=f"persistent tile {tile} conv {(n, cin, h, w, cout, k, ups)}")
-    finally:
-        lib.sdeo_debug_force_gemm_plan(C.c_int(-1), C.c_int(0))
-        lib.sdeo_debug_set_gemm_persist(C.c_int(0))
-
-
 HALO_TILES = {13: (8, 16, 80, 4), 14: (8, 16, 160, 4), 15: (8, 8, 80, 4), 16: (8, 8, 160, 4), 17: (8, 16, 64, 4), 18: (8, 16, 128, 4),
               22: (8, 16, 80, 8), 23: (8, 16, 160, 8), 24: (8, 16, 64, 8), 25: (8, 16, 128, 8)}   # kTiles index -> (PH, PW, BN, MFMA waves)
 

@@ -105,3 +105,26 @@ def test_shard_indices_properties():
 def test_single_process_passthrough():
     z = torch.randn(3, 4, 8, 8)
     assert gather_latents(z, 3) is z
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` needs no external launcher: the parent (which never touches a device) starts one child per GPU with
+    the torch.distributed environment set.  The children only report that environment here (SDEO_BENCH_ECHO_ENV)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = str(tmp_path / "env")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["SDEO_BENCH_ECHO_ENV"] = base
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, timeout=300)
+    assert r.returncode == 0
+    got = [json.load(open(f"{base}.{i}")) for i in range(2)]
+    assert [g["RANK"] for g in got] == ["0", "1"] and [g["LOCAL_RANK"] for g in got] == ["0", "1"]
+    assert all(g["WORLD_SIZE"] == "2" and g["MASTER_ADDR"] == "127.0.0.1" for g in got)
+    assert got[0]["MASTER_PORT"] == got[1]["MASTER_PORT"] and int(got[0]["MASTER_PORT"]) > 0
+    # under an external launcher (RANK already set) nothing is spawned: the process reports its own environment
+    env2 = dict(env, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", SDEO_BENCH_ECHO_ENV=base + "x")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env2, timeout=300)
+    assert r.returncode == 0 and json.load(open(base + "x.1"))["MASTER_PORT"] == "29511" and not os.path.exists(base + "x.0")

@@ -11,8 +11,10 @@ profiles/README.md).  tools/step_counters_summary.py turns the rocpd databases i
 import os
 import sys
 
-os.environ["SDEO_GRAPH"] = "0"
-os.environ["SDEO_OVERLAP"] = "0"
+# SDEO_STEPCTR_GRAPH / SDEO_STEPCTR_OVERLAP = 1 switch ONE of the two back on (tools/gpu_session.sh pmc_graph_only / pmc_overlap_only:
+# which of them the round-1 rocprofv3 crash needs)
+os.environ["SDEO_GRAPH"] = os.environ.get("SDEO_STEPCTR_GRAPH", "0")
+os.environ["SDEO_OVERLAP"] = os.environ.get("SDEO_STEPCTR_OVERLAP", "0")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch                                                        # noqa: E402
 from stablediffusioneo_amd import spec as S                        # noqa: E402
@@ -45,7 +47,8 @@ def marker():
 
 
 z = None
-for steps in (2, 2, 6):
+short = "short" in sys.argv[2:]
+for steps in ((2, 4) if short else (2, 2, 6)):
     z, _ = DDIMSampler(m).sample(steps, 1, (4, h, w), cond, verbose=False, eta=0.0, unconditional_guidance_scale=9.0,
                                  unconditional_conditioning=unc, x_T=x_T)
     torch.cuda.synchronize()
