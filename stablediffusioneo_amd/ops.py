@@ -103,7 +103,7 @@ def conv2d_gn(x, w_krsc, gamma, beta, bias=None, res=None, stride=1, upsample2x=
     y = torch.empty((n, ho, wo, cout), dtype=torch.float16, device=x.device)
     yn = torch.empty_like(y)
     pf = n * (ho * wo) * groups * 2 // 16 + n * groups * 2 + 1024           # tiles hold >= 32 rows: more than any plan needs
-    part = torch.zeros(pf, dtype=torch.float32, device=x.device)
+    part = torch.empty(pf, dtype=torch.float32, device=x.device)
     slots = C.c_int(0)
     check(lib.sdeo_debug_conv2d_gn_f16(ptr(yn), ptr(y), ptr(x), ptr(w_krsc), ptr(bias), ptr(res), _i(n), _i(h), _i(w), _i(cin), _i(cout),
                                        _i(k), _i(stride), _i(int(upsample2x)), ptr(gamma), ptr(beta), _i(groups), _f(eps), _i(int(swish)),

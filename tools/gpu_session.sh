@@ -7,6 +7,7 @@
 #         bench             bench.py --steps 5 --warmup 1 with roofline + cpu baseline + per-shape dump -> bench.json, profile.json
 #         quick[:flags]     bench.py --steps 3 --warmup 1 --no-cpu-baseline --fast-weights --no-roofline [flags, comma separated]
 #         ab:<ENV=V>        the quick bench twice, without and with the environment setting (same box A/B)
+#         profile[:flags]   per-(kernel, shape) table of one eagerly profiled image (in-library HIP events) -> profile_<n>.json
 #         kt                rocprofv3 --kernel-trace --stats of the bench command -> kernel_stats.csv, timeline.txt
 #         gemm_counters     per-shape SQ / FETCH / WRITE counter passes (tools/gemm_counters.py) -> gemm_counters.json
 #         step_counters     whole-step counter passes, eager + one stream (tools/step_counters.py) -> step_counters.json
@@ -25,6 +26,11 @@ s_bench() { timeout -k 10 700 python bench.py --steps 5 --warmup 1 --dump-profil
 s_quick() { name=$1; shift; timeout -k 10 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --fast-weights --no-roofline "$@" > $OUT/quick_$name.json 2> $OUT/quick_$name.err; rc=$?
   python -c "
 import json; b=json.load(open('$OUT/quick_$name.json')); print('quick $name', b['value'], 'img/s', b.get('ms_per_unet_step'), 'ms/step')"; return $rc; }
+s_profile() { timeout -k 10 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --fast-weights --dump-profile $OUT/profile_$1.json "${@:2}" > $OUT/profile_bench_$1.json 2> $OUT/profile_$1.err; rc=$?
+  python -c "
+import json; d=json.load(open('$OUT/profile_$1.json')); tot=sum(x['total_ms'] for x in d); n=sum(x['launches'] for x in d)
+print('profile: %.1f ms eager per image, %d launches' % (tot, n))
+for x in d[:40]: print('%-64s n=%5d ms=%7.2f us=%6.1f' % (x['kernel'][:64], x['launches'], x['total_ms'], 1e3*x['total_ms']/x['launches']))"; return $rc; }
 s_kt() { cd /tmp; export TMPDIR=/tmp; timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/bench_under_rocprof.json 2> $OUT/kt.err; rc=$?; cd $R
   tail -2 $OUT/kt.err; db=$(find $OUT/kt -name "*.db" | head -1)
   python tools/rocpd_summary.py stats $db $OUT/kernel_stats.csv > $OUT/kernel_stats.txt 2>&1; python tools/timeline.py $db 9200 > $OUT/timeline.txt 2>&1
@@ -54,11 +60,13 @@ for st in "$@"; do
   N=$((N + 1))
   case $st in
     pytest) step pytest s_pytest "" "" ;;
-    pytest:*) step "$st" s_pytest "${st#pytest:}" _$N ;;
+    pytest:*) step "$st" s_pytest "$(echo "${st#pytest:}" | tr "," " ")" _$N ;;
     bench) step bench s_bench ;;
     quick) step quick s_quick $N ;;
     quick:*) step "$st" s_quick $N $(echo "${st#quick:}" | tr ',' ' ') ;;
     ab:*) kv=${st#ab:}; step "ab off" s_quick ${N}_off; step "ab $kv" env $kv bash -c "$(declare -f s_quick); OUT=$OUT; s_quick ${N}_on" ;;
+    profile) step profile s_profile $N ;;
+    profile:*) step "$st" s_profile $N $(echo "${st#profile:}" | tr ',' ' ') ;;
     kt) step kt s_kt ;;
     gemm_counters) step gemm_counters s_gemm_counters ;;
     step_counters) step step_counters s_step_counters ;;
