@@ -41,6 +41,12 @@ extern "C" {
 typedef struct sdeo_handle_s* sdeo_handle;
 
 const char* sdeo_last_error(void);
+/* ABI version: bumped whenever the meaning of an argument of an existing entry point changes (not only its C type), so that a binding
+ * built against an older header fails loudly instead of computing with re-interpreted operands.
+ *   100  first release
+ *   101  sdeo_attention_f16 / sdeo_attention_causal_f16: arguments 7, 8, 14 are V ROW-MAJOR with its row stride and per-batch row count
+ *        (they were V transposed, ldvt and the batch stride of V^T) */
+#define SDEO_ABI_VERSION 101
 int sdeo_version(void);
 /* GEMM plan table: (tile, split-K) per problem shape key {M,N,K,Cin,R,stride,ups,Hi,Wi,B}.  Known shapes come from the
  * table, which stablediffusioneo_amd/tuned_plans_gfx950.json pre-loads so that runs are reproducible and start fast;

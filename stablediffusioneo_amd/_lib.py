@@ -62,6 +62,10 @@ def load(path: str = LIB_PATH):
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     if missing:
         raise SdeoError(f"libsdeo.so does not export {missing}")
+    want = int(re.search(r"#define\s+SDEO_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    if lib.sdeo_version() != want:
+        raise SdeoError(f"{path} reports ABI version {lib.sdeo_version()}, include/sdeo.h declares {want}: rebuild the library "
+                        f"(operand semantics changed between versions)")
     lib.sdeo_last_error.restype = C.c_char_p
     for name in ("sdeo_groupnorm_workspace_bytes", "sdeo_conv2d_workspace_bytes", "sdeo_gemm_workspace_bytes",
                  "sdeo_device_bytes", "sdeo_clip_device_bytes"):

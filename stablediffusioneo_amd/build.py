@@ -39,15 +39,14 @@ def _digest(path):
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = True, debug: bool = False, single: bool = False) -> str:
-    """debug: the measurement build (libsdeo_dbg.so); single: kernel arguments hold ONE problem instead of a pair
-    (libsdeo_single.so, -DSDEO_PAIR_SLOTS=1: pair launches fall back to two launches) for A/B measurements"""
-    out = OUT.replace("libsdeo.so", "libsdeo_dbg.so") if debug else (OUT.replace("libsdeo.so", "libsdeo_single.so") if single else OUT)
-    objdir = OBJ + "_dbg" if debug else (OBJ + "_single" if single else OBJ)
-    flags = FLAGS + (["-DSDEO_DEBUG_KERNELS"] if debug else []) + (["-DSDEO_PAIR_SLOTS=1"] if single else [])
+def build(force: bool = False, verbose: bool = True, debug: bool = False) -> str:
+    """debug: the measurement build (libsdeo_dbg.so)"""
+    out = OUT.replace("libsdeo.so", "libsdeo_dbg.so") if debug else OUT
+    objdir = OBJ + "_dbg" if debug else OBJ
+    flags = FLAGS + (["-DSDEO_DEBUG_KERNELS"] if debug else [])
     os.makedirs(objdir, exist_ok=True)
     stamp = os.path.join(objdir, "stamp")
-    dig = _digest(CSRC) + ("-dbg" if debug else "") + ("-single" if single else "")
+    dig = _digest(CSRC) + ("-dbg" if debug else "")
     if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == dig:
         return out
     srcs = _sources()
@@ -78,5 +77,3 @@ if __name__ == "__main__":
     build(force="--force" in sys.argv)
     if "--debug" in sys.argv:
         build(force="--force" in sys.argv, debug=True)
-    if "--single" in sys.argv:
-        build(force="--force" in sys.argv, single=True)

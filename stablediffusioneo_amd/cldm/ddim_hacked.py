@@ -76,7 +76,11 @@ class DDIMSampler(object):
         """`cldm/ddim_hacked.py:23-52`.  The buffers depend only on (steps, discretisation, eta) and the model's schedule, so a repeat
         call with the same arguments keeps them: the reference rebuilds them for every image, which here would cost a stream
         synchronisation (the pageable host -> device copies below) and leave the GPU idle between two images."""
-        key = (int(ddim_num_steps), str(ddim_discretize), float(ddim_eta), id(self.model), self.ddpm_num_timesteps)
+        # ... and the model's schedule: the tensor object, its in-place version counter and its storage identify what the buffers
+        # were computed from (a re-registered or reloaded schedule on the same model object must not reuse stale alphas / sigmas)
+        ac = self.model.alphas_cumprod
+        fp = (id(ac), int(getattr(ac, "_version", 0)), int(ac.data_ptr()) if isinstance(ac, torch.Tensor) else 0, tuple(ac.shape))
+        key = (int(ddim_num_steps), str(ddim_discretize), float(ddim_eta), id(self.model), self.ddpm_num_timesteps, fp)
         if getattr(self, "_schedule_key", None) == key:
             return
         self._schedule_key = None
@@ -100,6 +104,7 @@ class DDIMSampler(object):
         self.register_buffer("sqrt_recipm1_alphas_cumprod", f32(torch.sqrt(1. / ac - 1)))
         sigmas, alphas, alphas_prev = make_ddim_sampling_parameters(alphacums=ac.numpy(), ddim_timesteps=self.ddim_timesteps,
                                                                     eta=ddim_eta, verbose=verbose)
+        self._sigmas_all_zero = bool(float(np.abs(np.asarray(sigmas)).max()) == 0.0)      # host-side, once per schedule (loop-graph gate)
         self.register_buffer("ddim_sigmas", sigmas)
         self.register_buffer("ddim_alphas", alphas)
         self.register_buffer("ddim_alphas_prev", alphas_prev)
@@ -196,9 +201,7 @@ class DDIMSampler(object):
             return False
         if self.model.parameterization != "eps":
             return False
-        sig = self.ddim_sigmas
-        sig = sig.detach().cpu().numpy() if isinstance(sig, torch.Tensor) else np.asarray(sig)
-        return float(np.abs(sig).max()) == 0.0
+        return bool(getattr(self, "_sigmas_all_zero", False))      # computed with the schedule: no device -> host copy per image
 
     def _loop_graphed(self, img, c, uc, scale, time_range, total_steps, log_every_t, intermediates):
         """The loop of `cldm/ddim_hacked.py:137-160` with step 1 run eagerly (it computes the hint block and the context K / V of

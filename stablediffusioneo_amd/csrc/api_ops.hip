@@ -30,7 +30,7 @@ static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); 
 extern "C" {
 
 const char* sdeo_last_error(void) { return g_last_error.c_str(); }
-int sdeo_version(void) { return 100; }
+int sdeo_version(void) { return SDEO_ABI_VERSION; }
 void sdeo_debug_force_gemm_plan(int tile, int splitk) { conv_gemm_debug_force(tile, splitk); }
 void sdeo_debug_force_gemm_order(int order) { conv_gemm_debug_force_order(order); }
 void sdeo_set_tuned_gemm_plan(const int* key10, int tile, int splitk) { conv_gemm_set_tuned(key10, tile, splitk); }

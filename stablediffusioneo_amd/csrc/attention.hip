@@ -43,10 +43,7 @@ struct AP {
   int causal;        // 1: key j is visible to query t only when j <= t (CLIP text transformer)
 };
 
-#ifndef SDEO_PAIR_SLOTS
-#define SDEO_PAIR_SLOTS 2
-#endif
-struct AP2 { AP k[SDEO_PAIR_SLOTS]; };
+struct AP2 { AP k[1]; };
 
 // KS = 1: four waves, each owning 32 queries and walking all keys.  KS = 2 ("key split"): eight waves, the two waves of a
 // pair own the same 32 queries and each takes one 32-key half of every staged tile, so the serial per-tile chain
@@ -55,7 +52,7 @@ struct AP2 { AP k[SDEO_PAIR_SLOTS]; };
 template <int D16, int KS>
 __global__ __launch_bounds__(256 * KS, (KS == 2 ? (D16 <= 4 ? 4 : 2) : (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))))
 void attention_kernel(const AP2 pp) {
-  const AP& p = pp.k[blockIdx.y];      // pair launch: two problems of one shape, see KP2 in conv_inl.h
+  const AP& p = pp.k[blockIdx.y];      // blockIdx.y is always 0 (one problem per launch)
   constexpr int NT = 256 * KS;                               // threads per workgroup
   constexpr int NKB = 2 / KS;                                // 32-key blocks of a tile each wave handles
   constexpr int DT = (D16 + 1) / 2;                          // 32-row tiles of O^T
@@ -535,10 +532,10 @@ static int launch_attn_wide(const AP& ap, int B, hipStream_t stream) {
   constexpr int D = 4 * DS;
   constexpr int smem = 2 * (32 * (D * 2 + 16) + 32 * (D * 2 + 64)) + 4 * 64 * 16 * 4;
   static_assert(smem <= 160 * 1024, "LDS");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_done;
+  if (attr_done.need()) {
     SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_wide_kernel<DS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_done = true;
+    attr_done.mark();
   }
   hipLaunchKernelGGL((attention_wide_kernel<DS>), dim3(cdiv(ap.Tq, 32) * B * ap.H), dim3(256), smem, stream, ap);
   SDEO_HIP(hipGetLastError());
@@ -553,11 +550,11 @@ static int launch_attn_ks(const AP2& ap2, int count, int B, hipStream_t stream) 
   constexpr int stage2 = 2 * (64 * KROW + 64 * attn_vrow(DT));
   constexpr int merge = KS == 2 ? 4 * (2 + DT * 16) * 64 * 4 : 0;     // LDS of the key-half merge
   constexpr int smem = stage2 > merge ? stage2 : merge;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_done;
+  if (attr_done.need()) {
     SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<D16, KS>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_done = true;
+    attr_done.mark();
   }
   dim3 grid(cdiv(ap.Tq, 128) * B * ap.H, count);
   hipLaunchKernelGGL((attention_kernel<D16, KS>), grid, dim3(256 * KS), smem, stream, ap2);
@@ -619,21 +616,6 @@ int attention(const AttnArgs& a, hipStream_t stream) {
   if (a.d == 512) return launch_attn_wide<128>(ap.k[0], a.B, stream);
   if (a.d == 256) return launch_attn_wide<64>(ap.k[0], a.B, stream);
   return attn_dispatch(ap, 1, a.B, stream);
-}
-
-bool attention_can_pair(const AttnArgs& a, const AttnArgs& b) {
-  return SDEO_PAIR_SLOTS == 2 && a.d <= 160 && a.B == b.B && a.H == b.H && a.Tq == b.Tq && a.Tk == b.Tk && a.d == b.d && a.causal == b.causal;
-}
-
-int attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t stream) {
-  if (!attention_can_pair(a, b)) {
-    if (int rc = attention(a, stream)) return rc;
-    return attention(b, stream);
-  }
-  AP2 ap{};
-  if (int rc = attn_prepare(ap.k[0], a)) return rc;
-  if (int rc = attn_prepare(ap.k[SDEO_PAIR_SLOTS - 1], b)) return rc;
-  return attn_dispatch(ap, 2, a.B, stream);
 }
 
 int attention(f16* o, int ldo, const f16* q, int ldq, const f16* k, int ldk, const f16* v, int ldv, int B, int H,

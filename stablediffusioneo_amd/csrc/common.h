@@ -33,6 +33,23 @@ int fail(const char* fmt, ...);
       return ::sdeo::fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
   } while (0)
 
+// "done once" flag of a per-kernel, per-DEVICE setting (hipFuncSetAttribute(MaxDynamicSharedMemorySize) is recorded per device): a
+// process that drives a second GPU, or two host threads racing on first use, must not skip the call for a device that never
+// received it.  One atomic bit per device ordinal.
+struct DeviceOnce {
+  unsigned long long bits = 0;
+  bool need() const {               // true until mark() has been called on the current device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return !((__atomic_load_n(&bits, __ATOMIC_ACQUIRE) >> (dev & 63)) & 1ull);
+  }
+  void mark() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    __atomic_fetch_or(&bits, 1ull << (dev & 63), __ATOMIC_RELEASE);
+  }
+};
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -47,7 +47,12 @@ namespace sdeo {
 // a weight-tile row is 64 bytes per K-step instead of 128, one DMA pass of the 256 loading threads covers 64 rows, and the
 // MFMA waves widen each 8-byte fragment to fp16 in registers (v_cvt_scalef32_pk_f16_fp8, exact) right before its MFMAs.
 // The activations, the accumulation and the epilogue are those of the fp16 kernel; what changes is the bytes streamed.
-template <int BM, int BN, int STAGES, bool UPS, bool WS, bool W8 = false>
+// KPB (K-steps per barrier): the ring still holds STAGES 64-deep steps and every step is issued and retired as before, but loaders
+// and MFMA waves meet only once per GROUP of KPB steps: the loaders make a whole group visible with one counted wait + barrier and
+// then refill the KPB slots of the previous group.  A small tile has 10 - 20 MFMAs per wave per step (160 - 320 clocks) against a
+// barrier / wait skeleton of ~240 clocks per step; the halo kernel gained 14 - 35 % from the same change
+// (conv_halo.hip TPB).  Needs STAGES >= 2 KPB; STAGES - 2 KPB steps of loads stay in flight across a barrier.
+template <int BM, int BN, int STAGES, bool UPS, bool WS, bool W8 = false, int KPB = 1>
 __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2 pp) {
   const KP& p = pp.k[blockIdx.y];
   constexpr int BK = 64, RPP = 32;
@@ -55,8 +60,9 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
   constexpr int XP = BM / RPP, WP = (BN + WRPP - 1) / WRPP, L = XP + WP;     // DMA instructions per loading thread per stage
   constexpr int TM = BM / 2, TN = BN / 2, MI = TM / 16, NI = TN / 16;
   constexpr int XBYTES = BM * BK * 2, WBYTES = WP * 4096, STAGE = XBYTES + WBYTES;
-  constexpr int PF = STAGES - 1;                                // K-steps of loads issued ahead of the compute
-  static_assert(PF >= 1 && PF <= 7, "ring depth");
+  constexpr int PF = STAGES - KPB;                              // K-steps of loads issued ahead of the compute (initial fill)
+  constexpr int FLY = STAGES - 2 * KPB;                         // steps of loads that stay in flight across a barrier
+  static_assert(KPB >= 1 && FLY >= 0 && PF >= 1 && STAGES <= 10, "ring depth");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -187,13 +193,23 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
       if (++st_s == p.S) { st_s = 0; ++st_r; }
     }
   };
-  // retire the DMAs of K-step `it`: all but the (newer) steps still allowed in flight
-  auto retire = [&](int it) {
-    const int ahead = min(PF - 1, nk - 1 - it);
-    static_for<PF>([&](auto A) {
+  // retire the DMAs of group g (K-steps g KPB .. g KPB + KPB - 1): all but the (newer) steps still allowed in flight.  Steps are
+  // issued in order: PF in the prologue, then KPB more after every barrier, so behind group g at most FLY steps are younger.
+  auto retire = [&](int g) {
+    const int ahead = max(0, min(FLY, nk - (g + 1) * KPB));
+    static_for<FLY + 1>([&](auto A) {
       if (ahead == A.value) wait_vmcnt<A.value * L>();
     });
   };
+  // after barrier g every MFMA wave holds group g - 1 in registers: refill its slots (group 0: the KPB slots not used yet)
+  auto refill = [&](int g) {
+#pragma unroll
+    for (int j = 0; j < KPB; ++j) {
+      const int step = PF + g * KPB + j;
+      if (step < nk && !dbg_on(p, 8)) issue(step % STAGES);
+    }
+  };
+  const int ngroups = (nk + KPB - 1) / KPB;
 
   if constexpr (WS) {
     if (!do_mma) {                         // ---- loader waves
@@ -201,10 +217,10 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
 #pragma unroll
         for (int s = 0; s < PF; ++s)
           if (s < nk) issue(s);
-        for (int it = 0; it < nk; ++it) {
-          retire(it);
+        for (int g = 0; g < ngroups; ++g) {
+          retire(g);
           __builtin_amdgcn_s_barrier();
-          if (it + PF < nk && !dbg_on(p, 8)) issue((it + PF) % STAGES);
+          refill(g);
         }
       }
       __builtin_amdgcn_s_barrier();          // matches the MFMA waves' pre-epilogue barrier (LDS becomes epilogue scratch)
@@ -353,27 +369,36 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
         stamp(p, 2);
         reads0((g0 % STAGES) * STAGE);
         reads1((g0 % STAGES) * STAGE);
+        int ing = 1;                         // position of step it + 1 inside its group (KPB = 1: always 0 = opens a group)
         for (int it = 0; it < nk; ++it) {
           const bool more = it + 1 < nk;
+          if (ing == KPB) ing = 0;
+          const bool newgroup = KPB == 1 || ing == 0;      // step it + 1 opens a group: meet the loaders before reading it
           const unsigned sbn = ((g0 + it + 1) % STAGES) * STAGE;
           asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NI + MI) : "memory");
           __builtin_amdgcn_sched_barrier(0);
           if (!dbg_on(p, 4)) mma_half(wf0, xf0);
           __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-          if (more) {
-            __builtin_amdgcn_s_barrier();    // step it+1 visible; every MFMA wave holds step `it` in registers
-            reads0(sbn);
+          if (newgroup || !more) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+              __builtin_amdgcn_s_barrier();  // group of step it+1 visible; every MFMA wave holds step `it` in registers
+              reads0(sbn);
+            }
+          } else {
+            reads0(sbn);                     // same group, already visible: the half-1 fragments of step `it` only have to be in
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NI + MI) : "memory");     // registers (older than the NI + MI reads just issued)
           }
           __builtin_amdgcn_sched_barrier(0);
           if (!dbg_on(p, 4)) mma_half(wf1, xf1);
           __builtin_amdgcn_sched_barrier(0);
           if (more) reads1(sbn);
+          ++ing;
         }
       } else {
         for (int it = 0; it < nk; ++it) {
-          __builtin_amdgcn_s_barrier();      // step `it` visible (its loaders retired it before arriving here)
+          if (it % KPB == 0) __builtin_amdgcn_s_barrier();      // group of step `it` visible (its loaders retired it before arriving here)
           if (!dbg_on(p, 4)) compute(it);
         }
       }
@@ -382,9 +407,11 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
       for (int s = 0; s < PF; ++s)
         if (s < nk) issue(s);
       for (int it = 0; it < nk; ++it) {
-        retire(it);
-        __builtin_amdgcn_s_barrier();      // step `it` visible to every wave; everyone is done reading slot (it-1)%STAGES
-        if (it + PF < nk) issue((it + PF) % STAGES);
+        if (it % KPB == 0) {
+          retire(it / KPB);
+          __builtin_amdgcn_s_barrier();    // group of step `it` visible to every wave; everyone is done reading the previous group's slots
+          refill(it / KPB);
+        }
         compute(it);
       }
     }
@@ -682,8 +709,26 @@ static const TileCfg kTiles[] = {
     {32, 160, 64, 2, TK_DMA, 0.60f, 3, "conv_gemm_dma_kernel<32,160,2>"},
     {64, 64, 64, 3, TK_DMA, 0.65f, 3, "conv_gemm_dma_kernel<64,64,3>"},
     {128, 64, 64, 3, TK_DMA, 0.85f, 2, "conv_gemm_dma_kernel<128,64,3>/4w"},
+    // halo kernels with one barrier per filter row (three taps): indices 34..40 = kHaloCfgs 10..16
+    {128, 80, 64, 10, TK_HALO, 1.0f, 1, "conv3x3_halo_kernel<8,16,80,4,3>"},
+    {128, 80, 64, 11, TK_HALO, 1.0f, 1, "conv3x3_halo_kernel<8,16,80,8,3>"},
+    {128, 64, 64, 12, TK_HALO, 1.0f, 1, "conv3x3_halo_kernel<8,16,64,4,3>"},
+    {64, 80, 64, 13, TK_HALO, 1.0f, 1, "conv3x3_halo_kernel<8,8,80,4,3>"},
+    {64, 160, 64, 14, TK_HALO, 1.0f, 1, "conv3x3_halo_kernel<8,8,160,4,3>"},
+    {128, 128, 64, 15, TK_HALO, 1.0f, 1, "conv3x3_halo_kernel<8,16,128,8,3>"},
+    {128, 64, 64, 16, TK_HALO, 1.0f, 1, "conv3x3_halo_kernel<8,16,64,8,3>"},
+    // implicit-GEMM tiles with one barrier per GROUP of K-steps (conv_gemm_dma_kernel KPB): name<BM,BN,STAGES,KPB>
+    {32, 160, 64, 6, TK_DMA, 0.60f, 1, "conv_gemm_dma_kernel<32,160,6,k2>"},
+    {64, 64, 64, 8, TK_DMA, 0.65f, 1, "conv_gemm_dma_kernel<64,64,8,k2>"},
+    {64, 64, 64, 9, TK_DMA, 0.65f, 1, "conv_gemm_dma_kernel<64,64,9,k3>"},
+    {64, 160, 64, 5, TK_DMA, 0.90f, 1, "conv_gemm_dma_kernel<64,160,5,k2>"},
+    {128, 64, 64, 6, TK_DMA, 0.85f, 1, "conv_gemm_dma_kernel<128,64,6,k2>"},
+    {64, 64, 64, 6, TK_DMA, 0.65f, 1, "conv_gemm_dma_kernel<64,64,6,k2>"},
+    {128, 128, 64, 4, TK_DMA, 1.00f, 1, "conv_gemm_dma_kernel<128,128,4,k2>"},
+    {32, 160, 64, 5, TK_DMA, 0.60f, 1, "conv_gemm_dma_kernel<32,160,5,k2>"},
 };
-static const int kNumTiles = 34;
+static const int kNumTiles = 49;
+static bool tile_is_grouped(int t) { return t >= 41 && t <= 48; }
 static bool tile_is_light(int t) { return t >= 26 && t <= 33; }     // four-wave (non-specialised) instantiations
 static const int kNumCU = 256;
 
@@ -745,6 +790,7 @@ static Plan make_plan(const ConvGemm& p) {
     if (!usable(t)) continue;
     if (c.kind == TK_HALO && force_tile != t) continue;      // halo tiles enter through the measured plan table or a forced plan only
     if (tile_is_light(t) && force_tile != t) continue;       // so do the four-wave tiles
+    if (tile_is_grouped(t) && force_tile != t) continue;     // and the grouped-barrier tiles
     if (force_tile >= 0 && usable(force_tile) && force_tile != t) continue;
     const int tmn = plan_tiles_m(p, c), tnn = cdiv(p.N, c.bn);
     const int tiles = tmn * tnn;
@@ -813,10 +859,10 @@ const char* conv_gemm_kernel_name(const ConvGemm& p) { return kTiles[make_plan(p
 int conv_gemm_plan_splitk(const ConvGemm& p) { return make_plan(p).splitk; }
 
 template <typename K>
-static int launch_k(K kernel, int smem, bool* attr_done, const KP2& kp, int count, int tiles, hipStream_t stream, int threads = 256) {
-  if (!*attr_done) {
+static int launch_k(K kernel, int smem, DeviceOnce* attr_done, const KP2& kp, int count, int tiles, hipStream_t stream, int threads = 256) {
+  if (attr_done->need()) {
     SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    *attr_done = true;
+    attr_done->mark();
   }
   dim3 grid(tiles, count, kp.k[0].splitk);
   hipLaunchKernelGGL(kernel, grid, dim3(threads), smem, stream, kp);
@@ -833,18 +879,19 @@ static bool use_ws() {
 // fp8-weight instantiations: wave-specialised only, no folded Upsample (the weight-bound convs have neither)
 template <int BM, int BN, int ST>
 static int launch_dma_w8(const KP2& kp, int count, int tiles, hipStream_t stream) {
-  static bool done = false;
+  static DeviceOnce done;
   constexpr int smem = ST * (BM * 128 + (BN + 63) / 64 * 4096) + BM * 8;
   return launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, true, true>, smem, &done, kp, count, tiles, stream, 512);
 }
 
-template <int BM, int BN, int ST>
+template <int BM, int BN, int ST, int KPB = 1>
 static int launch_dma(int ups, const KP2& kp, int count, int tiles, hipStream_t stream) {
-  static bool done[4] = {false, false, false, false};
+  static DeviceOnce done[4];
   constexpr int smem = ST * (BM + BN) * 128 + BM * 8;      // ring + the LayerNorm row scalars (conv_gemm_dma_kernel: lnsm)
-  if (use_ws()) {
-    return ups ? launch_k(&conv_gemm_dma_kernel<BM, BN, ST, true, true>, smem, &done[3], kp, count, tiles, stream, 512)
-               : launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, true>, smem, &done[2], kp, count, tiles, stream, 512);
+  static_assert(smem <= 160 * 1024, "LDS");
+  if (use_ws() || KPB > 1) {
+    return ups ? launch_k(&conv_gemm_dma_kernel<BM, BN, ST, true, true, false, KPB>, smem, &done[3], kp, count, tiles, stream, 512)
+               : launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, true, false, KPB>, smem, &done[2], kp, count, tiles, stream, 512);
   }
   return ups ? launch_k(&conv_gemm_dma_kernel<BM, BN, ST, true, false>, smem, &done[1], kp, count, tiles, stream)
              : launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, false>, smem, &done[0], kp, count, tiles, stream);
@@ -853,7 +900,7 @@ static int launch_dma(int ups, const KP2& kp, int count, int tiles, hipStream_t 
 // four-wave workgroups on a two-slot ring (tiles 26..28)
 template <int BM, int BN, int ST>
 static int launch_dma_light(int ups, const KP2& kp, int count, int tiles, hipStream_t stream) {
-  static bool done[2] = {false, false};
+  static DeviceOnce done[2];
   constexpr int smem = ST * (BM + BN) * 128 + BM * 8;
   return ups ? launch_k(&conv_gemm_dma_kernel<BM, BN, ST, true, false>, smem, &done[1], kp, count, tiles, stream)
              : launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, false>, smem, &done[0], kp, count, tiles, stream);
@@ -944,8 +991,8 @@ static int prepare(const ConvGemm& p, Plan& pl, KP& kp) {
   return 0;
 }
 
-// launch `count` (1 or 2) problems that share plan `pl` (and the template instance: ups, fp8)
-static int dispatch(const Plan& pl, int ups, bool w8, const KP2& kp, int count, hipStream_t stream, bool no_reduce = false) {
+// launch the problem(s) in kp at plan `pl` (count is always 1)
+static int dispatch(const Plan& pl, int ups, bool w8, const KP2& kp, int count, hipStream_t stream) {
   const int tiles = pl.tiles_m * pl.tiles_n;
   int rc = 0;
   if (w8) {
@@ -963,8 +1010,8 @@ static int dispatch(const Plan& pl, int ups, bool w8, const KP2& kp, int count, 
     case 0: rc = launch_dma<128, 128, 3>(ups, kp, count, tiles, stream); break;
     case 1: rc = launch_dma<128, 64, 3>(ups, kp, count, tiles, stream); break;
     case 2: rc = launch_dma<64, 64, 4>(ups, kp, count, tiles, stream); break;
-    case 3: { static bool d = false; rc = launch_k(&conv_gemm_kernel<128, 64, 32, true>, 2 * (128 + 64) * 64, &d, kp, count, tiles, stream); break; }
-    case 4: { static bool d = false; rc = launch_k(&conv_gemm_kernel<64, 64, 32, true>, 2 * (64 + 64) * 64, &d, kp, count, tiles, stream); break; }
+    case 3: { static DeviceOnce d; rc = launch_k(&conv_gemm_kernel<128, 64, 32, true>, 2 * (128 + 64) * 64, &d, kp, count, tiles, stream); break; }
+    case 4: { static DeviceOnce d; rc = launch_k(&conv_gemm_kernel<64, 64, 32, true>, 2 * (64 + 64) * 64, &d, kp, count, tiles, stream); break; }
     case 5: rc = launch_dma<256, 128, 3>(ups, kp, count, tiles, stream); break;
     case 6: rc = launch_dma<64, 160, 3>(ups, kp, count, tiles, stream); break;
     case 7: rc = launch_dma<128, 160, 3>(ups, kp, count, tiles, stream); break;
@@ -984,13 +1031,22 @@ static int dispatch(const Plan& pl, int ups, bool w8, const KP2& kp, int count, 
     case 31: rc = launch_dma_light<32, 160, 2>(ups, kp, count, tiles, stream); break;
     case 32: rc = launch_dma_light<64, 64, 3>(ups, kp, count, tiles, stream); break;
     case 33: rc = launch_dma_light<128, 64, 3>(ups, kp, count, tiles, stream); break;
+    case 41: rc = launch_dma<32, 160, 6, 2>(ups, kp, count, tiles, stream); break;
+    case 42: rc = launch_dma<64, 64, 8, 2>(ups, kp, count, tiles, stream); break;
+    case 43: rc = launch_dma<64, 64, 9, 3>(ups, kp, count, tiles, stream); break;
+    case 44: rc = launch_dma<64, 160, 5, 2>(ups, kp, count, tiles, stream); break;
+    case 45: rc = launch_dma<128, 64, 6, 2>(ups, kp, count, tiles, stream); break;
+    case 46: rc = launch_dma<64, 64, 6, 2>(ups, kp, count, tiles, stream); break;
+    case 47: rc = launch_dma<128, 128, 4, 2>(ups, kp, count, tiles, stream); break;
+    case 48: rc = launch_dma<32, 160, 5, 2>(ups, kp, count, tiles, stream); break;
     case 13: case 14: case 15: case 16: case 17: case 18: case 22: case 23: case 24: case 25:
+    case 34: case 35: case 36: case 37: case 38: case 39: case 40:
       rc = launch_halo(kTiles[pl.tile].stages, kp, count, pl.tiles_m, pl.tiles_n, stream);
       break;
     default: return fail("conv_gemm: bad tile %d", pl.tile);
   }
   if (rc) return rc;
-  if (pl.splitk > 1 && !no_reduce) {
+  if (pl.splitk > 1) {
     const int64_t n = (int64_t)kp.k[0].M * (kp.k[0].N / 4);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(n, 256), count), dim3(256), 0, stream, kp);
     SDEO_HIP(hipGetLastError());
@@ -1002,27 +1058,7 @@ int conv_gemm(const ConvGemm& p, hipStream_t stream) {
   Plan pl;
   KP2 kk{};
   if (int rc = prepare(p, pl, kk.k[0])) return rc;
-  return dispatch(pl, p.ups, p.wscale != nullptr, kk, 1, stream, p.no_reduce != 0);
-}
-
-bool conv_gemm_can_pair(const ConvGemm& a, const ConvGemm& b) {
-  if (SDEO_PAIR_SLOTS != 2) return false;
-  if (key_of(a) != key_of(b) || a.S != b.S || a.pad != b.pad || a.Ho != b.Ho || a.Wo != b.Wo || a.no_reduce || b.no_reduce) return false;
-  if (a.force_tile != b.force_tile || a.force_splitk != b.force_splitk) return false;
-  const Plan pa = make_plan(a), pb = make_plan(b);
-  return pa.tile == pb.tile && pa.splitk == pb.splitk && pa.nk == pb.nk && pa.tiles_m == pb.tiles_m && pa.tiles_n == pb.tiles_n;
-}
-
-int conv_gemm_pair(const ConvGemm& a, const ConvGemm& b, hipStream_t stream) {
-  if (!conv_gemm_can_pair(a, b)) {
-    if (int rc = conv_gemm(a, stream)) return rc;
-    return conv_gemm(b, stream);
-  }
-  Plan pl, pl2;
-  KP2 kk{};
-  if (int rc = prepare(a, pl, kk.k[0])) return rc;
-  if (int rc = prepare(b, pl2, kk.k[SDEO_PAIR_SLOTS - 1])) return rc;
-  return dispatch(pl, a.ups, a.wscale != nullptr, kk, 2, stream);
+  return dispatch(pl, p.ups, p.wscale != nullptr, kk, 1, stream);
 }
 
 int conv_gemm_read_stamps(unsigned long long* out, int n) {
@@ -1072,7 +1108,7 @@ int conv_gemm_autotune(const ConvGemm& p, hipStream_t stream) {
   if (!is_fast(p) || g_force_tile >= 0 || g_force_splitk > 0) return 0;
   const ShapeKey key = key_of(p);
   if (g_tuned.count(key)) return 0;
-  static const int tiles[] = {0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33};
+  static const int tiles[] = {0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48};
   static const int sks[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20};
   hipEvent_t a, b;
   SDEO_HIP(hipEventCreate(&a));
@@ -1094,6 +1130,7 @@ int conv_gemm_autotune(const ConvGemm& p, hipStream_t stream) {
       ConvGemm q = p;
       q.force_tile = t;
       q.force_splitk = sk;
+      q.gn_out = nullptr;                              // candidates are timed without the GroupNorm partials (not every plan can emit them)
       if (int rc = conv_gemm(q, stream)) return rc;    // warm-up (also sets the function attributes)
       // best of two rounds of 8 back-to-back launches: single short rounds flipped plans from run to run
       const int reps = 8;
@@ -1108,6 +1145,9 @@ int conv_gemm_autotune(const ConvGemm& p, hipStream_t stream) {
         SDEO_HIP(hipEventElapsedTime(&t, a, b));
         ms = fminf(ms, t / reps);
       }
+      // a 3x3 conv of a ResBlock feeds a GroupNorm: a plan whose epilogue cannot emit the GroupNorm partials (split-K, strips that
+      // cut a group) costs that GroupNorm a statistics launch (~4 us, tools/plan_ab.py) where it runs as two launches (HW >= 1024)
+      if (p.R == 3 && p.N % 32 == 0 && p.Ho * p.Wo >= 1024 && p.y && conv_gemm_gn_slots(q, p.N / 32) == 0) ms += 0.004f;
       if (ms < best) { best = ms; pick = {t, make_plan(q).splitk}; }
     }
   }

@@ -20,15 +20,20 @@ namespace sdeo {
 
 constexpr int halo_xbytes(int ph, int pw) { return ((ph + 2) * (pw + 2) + 31) / 32 * 32 * 128; }
 constexpr int halo_wbytes(int bn) { return (bn + 31) / 32 * 32 * 128; }
-constexpr int halo_stages(int ph, int pw, int bn) {
-  const int s = (160 * 1024 - 2 * halo_xbytes(ph, pw)) / halo_wbytes(bn);
-  return s > 8 ? 8 : s;
+// ring slots; a slot holds the weights of TPB consecutive taps (TPB = 1: one barrier per tap; TPB = 3: one per filter row)
+constexpr int halo_stages(int ph, int pw, int bn, int tpb = 1) {
+  const int s = (160 * 1024 - 2 * halo_xbytes(ph, pw)) / (tpb * halo_wbytes(bn));
+  const int cap = tpb == 1 ? 8 : 4;
+  return s > cap ? cap : s;
 }
 
 // NMW = 4: one MFMA wave per SIMD beside one loader wave.  NMW = 8: two MFMA waves per SIMD (waves w and w + 4 share one), each
 // owning half as many pixels: an in-order wave alone on its SIMD exposes every fragment-read issue, wait and barrier between
 // its MFMA batches (measured 740 clocks per K-step for 320 clocks of MFMA); with a partner the SIMD interleaves the two.
-template <int PH, int PW, int BN, int NMW>
+// TPB = 3: the loaders and the MFMA waves meet at ONE barrier per filter row (three taps, 192-deep) instead of one per tap: the
+// per-step skeleton (counted wait + barrier + loop bookkeeping, ~120 ns per tap by the ablations of DESIGN.md section 11) is paid a
+// third as often and the MFMA waves run three taps of fragment reads and MFMAs without meeting the loaders.
+template <int PH, int PW, int BN, int NMW, int TPB = 1>
 __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP2 pp) {
   const KP& p = pp.k[blockIdx.y];
   constexpr int BM = PH * PW;
@@ -40,9 +45,10 @@ __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP2 
   constexpr int WBYTES = LW * 32 * 128;
   // weight ring as deep as LDS allows (<= 8 slots).  What bounds a K-step here is bytes in flight per CU, not bandwidth: a DMA
   // takes ~1 us to land under load, so a CU takes in (bytes in flight) / 1 us; 3 steps ahead gave ~40 GB/s, 7 give ~90.
-  constexpr int WST = halo_stages(PH, PW, BN), PF = WST - 1;
+  constexpr int WST = halo_stages(PH, PW, BN, TPB), PF = WST - 1;      // slots of TPB taps each; PF slots of loads ahead of the compute
   constexpr int WBASE = 2 * XBYTES;
-  static_assert(PF >= 2 && PF <= 8, "ring depth");
+  static_assert(TPB == 1 || TPB == 3, "taps per barrier");
+  static_assert(PF * TPB >= 2 && PF <= 8, "ring depth");
   static_assert(BM % (16 * NMW) == 0 && BN % 16 == 0, "tile");
   static_assert((NI + MI) * 8 + NI * MI * 4 <= 200, "fragment double-buffering needs the registers");
 
@@ -108,41 +114,47 @@ __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP2 
     };
     int st_tap = 0, st_ch = c0;                        // K-step the next issue_w stages
     auto issue_w = [&](int slot) {
-      char* dst = smem + WBASE + slot * WBYTES + lw * 1024;
-      const long koff = ((long)st_tap * p.Cin + (st_ch << 6)) * 2;
 #pragma unroll
-      for (int q = 0; q < LW; ++q) {
-        const char* src = wok[q] ? wsrc[q] + koff : zero;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + q * 4096), 16, 0, 0);
+      for (int tt = 0; tt < TPB; ++tt) {
+        char* dst = smem + WBASE + (slot * TPB + tt) * WBYTES + lw * 1024;
+        const long koff = ((long)st_tap * p.Cin + (st_ch << 6)) * 2;
+#pragma unroll
+        for (int q = 0; q < LW; ++q) {
+          const char* src = wok[q] ? wsrc[q] + koff : zero;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(dst + q * 4096), 16, 0, 0);
+        }
+        if (++st_tap == 9) { st_tap = 0; ++st_ch; }
       }
-      if (++st_tap == 9) { st_tap = 0; ++st_ch; }
     };
+    // a "step" of the loaders is one ring slot = TPB taps; SPS steps per Cin slice
+    constexpr int SPS = 9 / TPB, LWS = LW * TPB;
+    const int lsteps = nsteps / TPB;
     issue_x(0);
 #pragma unroll
-    for (int s = 0; s < PF; ++s) issue_w(s);           // nsteps >= 9 > PF
-    int tap = 0, cr = 0;                               // tap / relative Cin slice of K-step `it`
+    for (int s = 0; s < PF; ++s) issue_w(s);           // lsteps >= SPS > PF
+    int tap = 0, cr = 0;                               // step inside the slice / relative Cin slice of step `it`
     const int ncr = c1 - c0;
-    for (int it = 0; it < nsteps; ++it) {
+    for (int it = 0; it < lsteps; ++it) {
       // retire W(it) (and, being older, the patch of its slice).  Younger DMAs may stay in flight: the W stages of the next
       // min(PF-1, remaining) steps, plus the next slice's patch when it was issued in one of the last PF-1 iterations.
-      // (the patch is issued at tap 0 BEFORE that iteration's W stage, so it is younger than W(it) for taps 1 .. PF-1)
-      const int a = min(PF - 1, nsteps - 1 - it);
+      // (the patch is issued at step 0 of a slice BEFORE that iteration's W stage, so it is younger than W(it) for steps 1 .. PF-1)
+      const int a = min(PF - 1, lsteps - 1 - it);
       const bool xin = tap >= 1 && tap <= PF - 1 && cr + 1 < ncr;
       if (a == PF - 1) {
-        if (xin) wait_vmcnt<(PF - 1) * LW + LXW>();
-        else wait_vmcnt<(PF - 1) * LW>();
+        if (xin) wait_vmcnt<(PF - 1) * LWS + LXW>();
+        else wait_vmcnt<(PF - 1) * LWS>();
       } else {                                           // the last PF-1 steps: nothing is issued any more (xin is false there
         static_for<PF - 1>([&](auto A) {                 // unless the range has a single slice, where it is false anyway)
-          if (a == A.value) wait_vmcnt<A.value * LW>();
+          if (a == A.value) wait_vmcnt<A.value * LWS>();
         });
       }
       __builtin_amdgcn_s_barrier();
-      // every MFMA wave now holds K-step it-1 in registers: its W slot and (at tap 0) the previous slice's patch are free
-      if (dbg_on(p, 8)) { if (++tap == 9) { tap = 0; ++cr; } continue; }      // SDEO_DBG_GEMM ablation: no DMAs after the prologue
+      // every MFMA wave now holds step it-1 in registers: its W slot and (at step 0) the previous slice's patch are free
+      if (dbg_on(p, 8)) { if (++tap == SPS) { tap = 0; ++cr; } continue; }      // SDEO_DBG_GEMM ablation: no DMAs after the prologue
       if (tap == 0 && cr + 1 < ncr) issue_x((cr + 1) & 1);
-      if (it + PF < nsteps) issue_w((it + PF) % WST);
-      if (++tap == 9) { tap = 0; ++cr; }
+      if (it + PF < lsteps) issue_w((it + PF) % WST);
+      if (++tap == SPS) { tap = 0; ++cr; }
     }
     __builtin_amdgcn_s_barrier();            // matches the MFMA waves' pre-epilogue barrier
     return;
@@ -213,25 +225,32 @@ __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP2 
     reads0(std::integral_constant<int, 0>{}, 0u, 0u);
     reads1(std::integral_constant<int, 0>{}, 0u, 0u);
     int it = 0;
-    unsigned slot = 0;                       // W ring slot of K-step `it`
+    unsigned slot = 0;                       // W ring position (in taps: slot * TPB + tap inside the slot) of K-step `it`
     for (int cr = 0; cr < c1 - c0; ++cr) {
       const unsigned xcur = (cr & 1) * XBYTES;
       static_for<9>([&](auto T) {
         constexpr int NT = (T.value + 1) % 9;                     // tap of the next K-step
+        constexpr bool NEWSLOT = NT % TPB == 0;                   // the next K-step opens a ring slot: meet the loaders first
         const bool more = it + 1 < nsteps;
-        const unsigned nslot = slot + 1 == WST ? 0u : slot + 1;
+        const unsigned nslot = slot + 1 == WST * TPB ? 0u : slot + 1;
         const unsigned xnext = T.value == 8 ? (unsigned)XBYTES - xcur : xcur;
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NI + MI) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         mma_half(wf0, xf0);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        if (NEWSLOT) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (more) {
-          __builtin_amdgcn_s_barrier();      // K-step it+1 visible; every MFMA wave holds K-step `it` in registers
+          if (NEWSLOT) __builtin_amdgcn_s_barrier();      // the next slot is visible; every MFMA wave holds this slot's last tap in registers
           reads0(std::integral_constant<int, NT>{}, nslot * WBYTES, xnext);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (!NEWSLOT) {                      // no barrier here: the half-1 fragments only have to be in registers
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NI + MI) : "memory");     // (issued before the NI + MI reads of reads0 above)
+          __builtin_amdgcn_sched_barrier(0);
+        }
         mma_half(wf1, xf1);
         __builtin_amdgcn_sched_barrier(0);
         if (more) reads1(std::integral_constant<int, NT>{}, nslot * WBYTES, xnext);
@@ -247,8 +266,8 @@ __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP2 
   stamp(p, 3);
   stamp_cycles(p, 15);
   if (dbg_on(p, 32)) return;
-  static_assert(NMW * epilogue_scratch_bytes(BN) <= 2 * XBYTES + WST * WBYTES, "epilogue scratch");
-  constexpr int SCR = ((2 * XBYTES + WST * WBYTES) / NMW) & ~15;           // LDS each MFMA wave may use as epilogue scratch
+  static_assert(NMW * epilogue_scratch_bytes(BN) <= 2 * XBYTES + WST * TPB * WBYTES, "epilogue scratch");
+  constexpr int SCR = ((2 * XBYTES + WST * TPB * WBYTES) / NMW) & ~15;     // LDS each MFMA wave may use as epilogue scratch
   constexpr int NBLK = epilogue_blocks(BN, MI, SCR);
   epilogue_rows<NI, MI, BN, NBLK>(pe, acc, mrow, n0, fq, z, bpre, use_bpre, smem + wave * SCR);
   if (pe.gn_out) {                         // GroupNorm partials of this patch: the loader waves are gone, the barrier counts the rest
@@ -287,20 +306,28 @@ const HaloCfg kHaloCfgs[] = {
     {8, 16, 160, "conv3x3_halo_kernel<8,16,160,8>"},
     {8, 16, 64, "conv3x3_halo_kernel<8,16,64,8>"},
     {8, 16, 128, "conv3x3_halo_kernel<8,16,128,8>"},
+    // one barrier per filter row (TPB = 3)
+    {8, 16, 80, "conv3x3_halo_kernel<8,16,80,4,3>"},
+    {8, 16, 80, "conv3x3_halo_kernel<8,16,80,8,3>"},
+    {8, 16, 64, "conv3x3_halo_kernel<8,16,64,4,3>"},
+    {8, 8, 80, "conv3x3_halo_kernel<8,8,80,4,3>"},
+    {8, 8, 160, "conv3x3_halo_kernel<8,8,160,4,3>"},
+    {8, 16, 128, "conv3x3_halo_kernel<8,16,128,8,3>"},
+    {8, 16, 64, "conv3x3_halo_kernel<8,16,64,8,3>"},
 };
-const int kNumHaloCfgs = 10;
+const int kNumHaloCfgs = 17;
 
-template <int PH, int PW, int BN, int NMW>
+template <int PH, int PW, int BN, int NMW, int TPB = 1>
 static int launch_halo_t(const KP2& kp, int count, int tiles_m, int tiles_n, hipStream_t stream) {
-  constexpr int smem = 2 * halo_xbytes(PH, PW) + halo_stages(PH, PW, BN) * halo_wbytes(BN);
+  constexpr int smem = 2 * halo_xbytes(PH, PW) + halo_stages(PH, PW, BN, TPB) * TPB * halo_wbytes(BN);
   static_assert(smem <= 160 * 1024, "LDS");
-  static bool done = false;
-  if (!done) {
-    SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<PH, PW, BN, NMW>),
+  static DeviceOnce done;
+  if (done.need()) {
+    SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<PH, PW, BN, NMW, TPB>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    done = true;
+    done.mark();
   }
-  hipLaunchKernelGGL((conv3x3_halo_kernel<PH, PW, BN, NMW>), dim3(tiles_m * tiles_n, count, kp.k[0].splitk), dim3(NMW * 64 + 256), smem, stream,
+  hipLaunchKernelGGL((conv3x3_halo_kernel<PH, PW, BN, NMW, TPB>), dim3(tiles_m * tiles_n, count, kp.k[0].splitk), dim3(NMW * 64 + 256), smem, stream,
                      kp);
   SDEO_HIP(hipGetLastError());
   return 0;
@@ -318,6 +345,13 @@ int launch_halo(int variant, const KP2& kp, int count, int tiles_m, int tiles_n,
     case 7: return launch_halo_t<8, 16, 160, 8>(kp, count, tiles_m, tiles_n, stream);
     case 8: return launch_halo_t<8, 16, 64, 8>(kp, count, tiles_m, tiles_n, stream);
     case 9: return launch_halo_t<8, 16, 128, 8>(kp, count, tiles_m, tiles_n, stream);
+    case 10: return launch_halo_t<8, 16, 80, 4, 3>(kp, count, tiles_m, tiles_n, stream);
+    case 11: return launch_halo_t<8, 16, 80, 8, 3>(kp, count, tiles_m, tiles_n, stream);
+    case 12: return launch_halo_t<8, 16, 64, 4, 3>(kp, count, tiles_m, tiles_n, stream);
+    case 13: return launch_halo_t<8, 8, 80, 4, 3>(kp, count, tiles_m, tiles_n, stream);
+    case 14: return launch_halo_t<8, 8, 160, 4, 3>(kp, count, tiles_m, tiles_n, stream);
+    case 15: return launch_halo_t<8, 16, 128, 8, 3>(kp, count, tiles_m, tiles_n, stream);
+    case 16: return launch_halo_t<8, 16, 64, 8, 3>(kp, count, tiles_m, tiles_n, stream);
     default: return fail("launch_halo: bad variant %d", variant);
   }
 }

@@ -52,13 +52,8 @@ struct KP {
   int gn_cpg, gn_slots, gn_groups;
 };
 
-// What a kernel receives: one problem, or two independent problems of the SAME plan (grid, tile, split-K, template instance)
-// run by one launch, blockIdx.y selecting the problem ("pair launch": the ControlNet and the UNet encoder execute the same
-// sequence of shapes on different weights and activations, and at batch 1 a launch rarely fills the chip by itself).
-#ifndef SDEO_PAIR_SLOTS
-#define SDEO_PAIR_SLOTS 2
-#endif
-struct KP2 { KP k[SDEO_PAIR_SLOTS]; };
+// what a kernel receives (blockIdx.y indexes the problem; always one)
+struct KP2 { KP k[1]; };
 
 // Ablation / stamp switches exist only in the measurement build: in the production library dbg_on() is the constant false and
 // every branch on it (and the stamp code) is compiled out of the K loops.

@@ -31,7 +31,6 @@ struct ConvGemm {
                                // 3 GEGLU pair: W rows interleaved value/gate in blocks of 16, y gets N/2 columns v * gelu(g)
   int bias_per_row = 0;
   float scale = 1.0f;
-  int no_reduce = 0;           // split-K plans: leave the partial slabs in `workspace` (the consumer reduces them: GnReduce)
   int force_tile = -1;         // testing hook: tile config index
   int force_splitk = 0;
   // LayerNorm folded into the GEMM (see KP::ln_stats in conv_inl.h): x is used raw, w = W * gamma, bias = b + W beta,
@@ -55,10 +54,6 @@ struct ConvGemm {
 int conv_gemm(const ConvGemm& p, hipStream_t stream);
 // M tiles per image of the plan chosen for p when its epilogue can emit GroupNorm partials for groups of cpg channels, else 0
 int conv_gemm_gn_slots(const ConvGemm& p, int cpg);
-// Pair launch: two independent problems of one shape and plan in ONE launch (blockIdx.y selects the problem; a split-K plan
-// needs distinct workspaces).  Falls back to two launches when the plans differ.  Results are those of two single launches.
-bool conv_gemm_can_pair(const ConvGemm& a, const ConvGemm& b);
-int conv_gemm_pair(const ConvGemm& a, const ConvGemm& b, hipStream_t stream);
 // whether the plan chosen for p is a halo-reuse 3x3 kernel (which has no fp8-weight variant)
 bool conv_gemm_plan_is_halo(const ConvGemm& p);
 // strips (partials per row) a launch of p writes to stats_out; 0 when the chosen plan cannot emit them (split-K)
@@ -86,39 +81,20 @@ int gn_chunks(int HW);
 int groupnorm_nhwc(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const float* beta, int B, int HW, int C,
                    int groups, float eps, int with_silu, float* partials, hipStream_t stream);
 
-// x of a GroupNorm given as the fp32 partial slabs of a split-K conv / GEMM that has not been reduced yet (conv_gemm with
-// `no_reduce`): the single-launch GroupNorm sums the slabs, applies the conv's epilogue and writes x itself -- the arithmetic of
-// splitk_reduce_kernel in the same order, so the bits are those of the two separate launches, with one launch boundary less
-struct GnReduce {
-  const float* ws = nullptr;       // [splitk][M][N] partial sums (M = B * HW rows, N = C columns); null = x is read as usual
-  int splitk = 0;
-  const float* bias = nullptr;     // [N]
-  const float* bias2 = nullptr;    // [B][ld_bias2]
-  int ld_bias2 = 0;
-  const f16* res = nullptr;        // [M][ldres]
-  int ldres = 0;
-  float scale = 1.0f;
-  int act = 0;
-  const float* wscale = nullptr;   // [N] (fp8 weights)
-};
 struct GnArgs {
   f16* y; const f16* x; const float* gamma; const float* beta; float* partials;
   int ldy, ldx, B, HW, C, groups;
   float eps;
   int with_silu;
-  GnReduce red{};                  // with red.ws set, `x` is where the reduced tensor is WRITTEN (and normalised from LDS)
   // statistics already exist: ext_partials[b][ext_nsc][groups][2] = (sum, sumsq) partials written by the epilogue of the conv / GEMM
   // that produced x (ConvGemm::gn_out).  Then no statistics pass runs: ONE launch normalises (plus a small reduction launch when
   // ext_nsc > 128, the VAE's large images: `partials` is its workspace, >= B * groups * 2 floats)
   const float* ext_partials = nullptr;
   int ext_nsc = 0;
 };
-// whether groupnorm_nhwc(a) runs as ONE launch with its slice in LDS (the only form that can take GnReduce)
+// whether groupnorm_nhwc(a) runs as ONE launch with its slice in LDS
 bool groupnorm_is_single_launch(const GnArgs& a);
 int groupnorm_nhwc(const GnArgs& a, hipStream_t stream);
-// two GroupNorm problems of one shape in one launch (pair launch, see conv_gemm_pair); distinct `partials` required
-bool groupnorm_can_pair(const GnArgs& a, const GnArgs& b);
-int groupnorm_nhwc_pair(const GnArgs& a, const GnArgs& b, hipStream_t stream);
 
 // LayerNorm over the last dim of [rows][C] fp16 (two-pass in registers, fp32 math).
 int layernorm(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const float* beta, int rows, int C, float eps,
@@ -139,9 +115,6 @@ struct AttnArgs {
   int causal;
 };
 int attention(const AttnArgs& a, hipStream_t stream);
-// two attention problems of one shape in one launch (pair launch, see conv_gemm_pair); falls back to two launches otherwise
-bool attention_can_pair(const AttnArgs& a, const AttnArgs& b);
-int attention_pair(const AttnArgs& a, const AttnArgs& b, hipStream_t stream);
 // vt[c][b*TkSv + t] = v[(b*T + t)*ldv + c]   (VAE AttnBlock's materialised-score path)
 int transpose_pad(f16* vt, int ldvt, const f16* v, int ldv, int B, int T, int TkSv, int C, hipStream_t stream);
 

@@ -189,20 +189,8 @@ struct T {           // fp16 activation view: rows x c, row stride ld; (n,h,w) w
   int rows() const { return n * h * w; }
 };
 
-// What a launch is, for the ops that can share a launch with the same-shaped op of another program (pair launch:
-// merge_pairs): conv / GEMM, attention, GroupNorm.  Pointers into the workspaces are resolved at launch time (`sel`).
-struct PairDesc {
-  enum Kind { CONV, ATTN, GN } kind = CONV;
-  ConvGemm cg;
-  const float* scale_host = nullptr;
-  int sel = 0;
-  AttnArgs at{};
-  GnArgs gn{};
-};
-
 struct Op {          // one launch of a program + what it is for the profiler
   std::function<int(hipStream_t)> fn;
-  std::shared_ptr<PairDesc> pd;   // set when the op can be pair-launched
   const char* key = "other";
   std::string tag;           // problem shape, shown by the profiler when SDEO_PROFILE_DETAIL=1
   double flops = 0, bytes = 0;
@@ -275,19 +263,6 @@ struct sdeo_handle_s {
   bool use_control = true;
   // programs
   Program p_hint, p_ctx_cn, p_ctx_unet, p_cn, p_cn_export, p_ctrl_import, p_unet_enc, p_unet_dec, p_unet_noctrl, p_vae;
-  // the same four network programs with every [split-K conv, single-launch GroupNorm] pair fused (fuse_reduce_groupnorm): the
-  // GroupNorm sums the conv's partial slabs itself, the splitk_reduce launch between them disappears
-  Program f_cn, f_unet_enc, f_unet_dec, f_unet_noctrl;
-  bool fuse_rg = false;      // SDEO_FUSE_REDUCE_GN=1 / sdeo_debug_set_reduce_gn: run them (same bits).  Measured on one box: 6.71 ms per step
-                             // fused vs 6.69 ms unfused -- 31 launches fewer per pass, but the 64 workgroups of the GroupNorm read the
-                             // slabs slower than the reduce kernel's 160 - 640 did, so the saved boundaries are spent again
-  int fused_rg = 0;
-  // ControlNet and UNet encoder + middle block as ONE program: same-shaped ops of the two share a launch (merge_pairs)
-  Program p_pair;
-  bool pair = false;         // SDEO_PAIR=1 runs it instead of the two programs on two streams.  Measured on MI355X (same box, batch 1,
-                             // 512x512): 6.99 ms / UNet step paired vs 6.92 ms on two streams -- the launches are CU-throughput-bound at
-                             // their tuned plans, so sharing a launch only saves the boundary the second stream already hides.
-  int pair_launches = 0, pair_singles = 0;
   std::vector<size_t> ctrl_elems;
   size_t device_bytes = 0;
   // profiling (sdeo_profile_*): HIP events around every launch of the next programs
@@ -551,19 +526,18 @@ struct Builder {
   }
   // producer side of the GroupNorm fusion: when the plan of p can, give it a partials buffer and record it on the output tensor
   static bool gn_from_producer() { static const bool on = [] { const char* v = getenv("SDEO_GN_PRODUCER_STATS"); return !v || atoi(v) != 0; }(); return on; }
-  void want_gn_partials(ConvGemm& p, T& y, int images) {
-    const int G = 32;
-    if (!gn_from_producer() || p.N % G) return;
-    const int cpg = p.N / G, slots = conv_gemm_gn_slots(p, cpg);
-    if (slots <= 0) return;
-    y.gnp_off = arena->alloc((size_t)images * slots * G * 2 * sizeof(float));
-    y.gnp = reinterpret_cast<float*>(base + y.gnp_off);
-    y.gn_slots = slots;
-    p.gn_out = y.gnp; p.gn_cpg = cpg; p.gn_slots = slots; p.gn_groups = G;
+  // The buffer is reserved whatever the plan (sized for the smallest tile: 32 rows per entry), so that the arena plan does not depend
+  // on plans measured between the planning pass and the build pass (SDEO_AUTOTUNE); whether the launch emits is decided in
+  // launch_conv, after the plan of the shape is final.
+  void reserve_gn_partials(const ConvGemm& p, T& y) {
+    if (!gn_from_producer() || p.N % 32) return;
+    const int hw = p.Ho * p.Wo;
+    y.gnp_off = arena->alloc((size_t)p.B * ((hw + 31) / 32) * 32 * 2 * sizeof(float));
+    y.gnp = nullptr;                       // set by launch_conv when the plan emits
+    y.gn_slots = 0;
   }
-  void push(Op op, const char* key = "elementwise", double flops = 0, double bytes = 0, const std::string& tag = std::string(),
-            std::shared_ptr<PairDesc> pd = nullptr) {
-    op.key = key; op.flops = flops; op.bytes = bytes; op.tag = tag; op.pd = std::move(pd);
+  void push(Op op, const char* key = "elementwise", double flops = 0, double bytes = 0, const std::string& tag = std::string()) {
+    op.key = key; op.flops = flops; op.bytes = bytes; op.tag = tag;
     if (!dry) prog->push_back(std::move(op));
   }
 
@@ -578,7 +552,7 @@ struct Builder {
   const float* named_v(const std::string& name) { return reinterpret_cast<const float*>(e->wslab + e->named_off.at(name)); }
 
 
-  void launch_conv(ConvGemm p, const float* scale_host, RowStats* stats = nullptr) {
+  void launch_conv(ConvGemm p, const float* scale_host, RowStats* stats = nullptr, T* gn_y = nullptr) {
     if (e->weight_bits == 8 && p.M <= 512 && p.Cin % 64 == 0 && !p.ups && !p.bias_per_row && !conv_gemm_plan_is_halo(p)) {
       // weight-bound shapes stream the fp8 copy of their matrix (same numbers: the fp16 copy holds the dequantised values); where
       // the measured fp16 plan is a halo-reuse 3x3 kernel (activation-bound: M = 512 at long K) that kernel keeps the job
@@ -598,6 +572,14 @@ struct Builder {
       q.workspace_bytes = e->splitk_ws_bytes;
       if (conv_gemm_autotune(q, 0) && err.empty()) err = std::string("autotune failed: ") + sdeo_last_error();
     }
+    if (gn_y && gn_y->gnp_off != (size_t)-1) {      // the plan of this shape is final now: emit the GroupNorm partials if it can
+      const int cpg = p.N / 32, slots = conv_gemm_gn_slots(p, cpg);
+      if (slots > 0) {
+        gn_y->gnp = reinterpret_cast<float*>(base + gn_y->gnp_off);
+        gn_y->gn_slots = slots;
+        p.gn_out = gn_y->gnp; p.gn_cpg = cpg; p.gn_slots = slots; p.gn_groups = 32;
+      }
+    }
     if (!dry && getenv("SDEO_DUMP_GEMM"))   // shape census for tools/tune_gemm.py
       fprintf(stderr, "SDEO_GEMM %d %d %d %d %d %d %d %d %d %d %s\n", p.M, p.N, p.K, p.Cin, p.R, p.stride, p.ups, p.B, p.Hi, p.Wi,
               conv_gemm_kernel_name(p));
@@ -611,8 +593,6 @@ struct Builder {
     }
     Engine* eng = e;
     const int sel = ws_sel;
-    auto pd = std::make_shared<PairDesc>();
-    pd->kind = PairDesc::CONV; pd->cg = p; pd->scale_host = scale_host; pd->sel = sel;
     push([p, scale_host, eng, sel](hipStream_t s) mutable {
       p.workspace = sel ? eng->splitk_ws2 : eng->splitk_ws;
       p.workspace_bytes = eng->splitk_ws_bytes;
@@ -621,7 +601,7 @@ struct Builder {
     }, conv_gemm_kernel_name(p), 2.0 * p.M * p.N * p.K,
        2.0 * ((double)p.M * p.Cin * (p.R * p.S > 1 ? 1 : 1) + (double)p.N * p.K + (double)p.M * p.N),
        "M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) + " R" + std::to_string(p.R) + " s" +
-           std::to_string(p.stride) + " u" + std::to_string(p.ups), pd);
+           std::to_string(p.stride) + " u" + std::to_string(p.ups));
     if (stats_by_kernel) {
       float* sp = stats->p; const int ld = stats->ld, rows = p.M, C = p.N, ldy = p.ldy; const f16* y = p.y;
       push([=](hipStream_t s) { return row_stats(sp, ld, y, ldy, rows, C, s); }, "row_stats", 0, 2.0 * rows * C,
@@ -665,8 +645,9 @@ struct Builder {
     p.B = x.n; p.Hi = x.h; p.Wi = x.w; p.Cin = x.c; p.Ho = ho; p.Wo = wo; p.R = p.S = k; p.stride = stride; p.pad = pad; p.ups = ups;
     p.M = x.n * ho * wo; p.N = cs; p.K = k * k * x.c;
     p.ldx = x.ld; p.ldw = p.K; p.ldy = y.ld; p.act = o.act;
-    if (o.gn_next && !o.out && !o.scale_host && cs == y.c) want_gn_partials(p, y, x.n);
-    launch_conv(p, o.scale_host, o.stats);
+    const bool want_gn = o.gn_next && !o.out && !o.scale_host && cs == y.c;
+    if (want_gn) reserve_gn_partials(p, y);
+    launch_conv(p, o.scale_host, o.stats, want_gn ? &y : nullptr);
     T r = y;
     if (o.out) r.off = (size_t)-1;
     return r;
@@ -711,12 +692,10 @@ struct Builder {
     Engine* eng = e;
     const int sel = ws_sel;
     const f16* xp = x.p; f16* yp = y.p; const int ldx = x.ld, ldy = y.ld;
-    auto pd = std::make_shared<PairDesc>();
-    pd->kind = PairDesc::GN; pd->sel = sel;
-    pd->gn = GnArgs{yp, xp, g, b, nullptr, ldy, ldx, B, HW, C, 32, eps, silu_};
-    if (x.gnp && !groupnorm_is_single_launch(pd->gn)) {
+    const GnArgs gargs{yp, xp, g, b, nullptr, ldy, ldx, B, HW, C, 32, eps, silu_};
+    if (x.gnp && !groupnorm_is_single_launch(gargs)) {
       // the statistics came out of the producer's epilogue: one launch (normalise) instead of two
-      GnArgs ga = pd->gn;
+      GnArgs ga = gargs;
       ga.ext_partials = x.gnp; ga.ext_nsc = x.gn_slots;
       max_gn = std::max(max_gn, (size_t)B * 32 * 2 * sizeof(float));
       push([=](hipStream_t s) mutable { ga.partials = sel ? eng->gn_ws2 : eng->gn_ws; return groupnorm_nhwc(ga, s); }, "groupnorm", 0,
@@ -725,7 +704,7 @@ struct Builder {
       return y;
     }
     push([=](hipStream_t s) { return groupnorm_nhwc(yp, ldy, xp, ldx, g, b, B, HW, C, 32, eps, silu_, sel ? eng->gn_ws2 : eng->gn_ws, s); }, "groupnorm", 0,
-         3.0 * 2.0 * B * HW * C, "C" + std::to_string(C) + " HW" + std::to_string(HW), pd);
+         3.0 * 2.0 * B * HW * C, "C" + std::to_string(C) + " HW" + std::to_string(HW));
     if (out) y.off = (size_t)-1;
     return y;
   }
@@ -743,12 +722,9 @@ struct Builder {
   void attn(const T& o, const f16* q, int ldq, const f16* k, int ldk, const f16* v, int ldv, int B, int H, int Tq, int Tk, int TkS, int TkSv, int d) {
     f16* op = o.p; const int ldo = o.ld;
     const float scale = 1.0f / sqrtf((float)d);
-    auto pd = std::make_shared<PairDesc>();
-    pd->kind = PairDesc::ATTN;
-    pd->at = AttnArgs{op, q, k, v, ldo, ldq, ldk, ldv, B, H, Tq, Tk, TkS, TkSv, d, scale, 0};
     push([=](hipStream_t s) { return attention(op, ldo, q, ldq, k, ldk, v, ldv, B, H, Tq, Tk, TkS, TkSv, d, scale, s); }, "attention",
          4.0 * B * H * (double)Tq * Tk * d, 2.0 * B * H * d * (2.0 * Tq + 2.0 * Tk),
-         "Tq" + std::to_string(Tq) + " Tk" + std::to_string(Tk) + " d" + std::to_string(d), pd);
+         "Tq" + std::to_string(Tq) + " Tk" + std::to_string(Tk) + " d" + std::to_string(d));
   }
 };
 
@@ -895,115 +871,6 @@ static int run(Engine* e, const Program& p, hipStream_t s) {
     e->prof.push_back(r);
   }
   return 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Pair launches.  ControlNet is a copy of the UNet encoder + middle block (`cldm/cldm.py:54-282`): given (x, t, context) the two run
-// the same sequence of problem shapes on different weights and activations, and neither reads the other's results before the
-// decoder.  At batch 1 most of those launches neither fill the 256 CUs nor outlast their own fixed cost, so the two programs are
-// zipped into one: ops at matching positions whose kernels, plans and grids coincide share ONE launch (blockIdx.y = problem),
-// everything else (zero convs, hint add ...) keeps its own launch.  Each list is consumed in order, so every op still runs after
-// all of its own program's predecessors; the arithmetic of each problem is untouched (bit-identical to the unpaired programs).
-// ------------------------------------------------------------------------------------------------
-static bool can_pair(const Op& a, const Op& b) {
-  if (!a.pd || !b.pd || a.pd->kind != b.pd->kind) return false;
-  switch (a.pd->kind) {
-    case PairDesc::CONV: return a.pd->sel != b.pd->sel && conv_gemm_can_pair(a.pd->cg, b.pd->cg);
-    case PairDesc::ATTN: return attention_can_pair(a.pd->at, b.pd->at);
-    case PairDesc::GN: return a.pd->sel != b.pd->sel && groupnorm_can_pair(a.pd->gn, b.pd->gn);
-  }
-  return false;
-}
-
-static Op make_pair_op(Engine* eng, const Op& a, const Op& b) {
-  std::shared_ptr<PairDesc> pa = a.pd, pb = b.pd;
-  Op op([eng, pa, pb](hipStream_t s) {
-    switch (pa->kind) {
-      case PairDesc::CONV: {
-        ConvGemm q[2] = {pa->cg, pb->cg};
-        const PairDesc* d[2] = {pa.get(), pb.get()};
-        for (int i = 0; i < 2; ++i) {
-          q[i].workspace = d[i]->sel ? eng->splitk_ws2 : eng->splitk_ws;
-          q[i].workspace_bytes = eng->splitk_ws_bytes;
-          if (d[i]->scale_host) q[i].scale = *d[i]->scale_host;
-        }
-        return conv_gemm_pair(q[0], q[1], s);
-      }
-      case PairDesc::ATTN: return attention_pair(pa->at, pb->at, s);
-      case PairDesc::GN: {
-        GnArgs g0 = pa->gn, g1 = pb->gn;
-        g0.partials = pa->sel ? eng->gn_ws2 : eng->gn_ws;
-        g1.partials = pb->sel ? eng->gn_ws2 : eng->gn_ws;
-        return groupnorm_nhwc_pair(g0, g1, s);
-      }
-    }
-    return 0;
-  });
-  op.key = a.key; op.flops = a.flops + b.flops; op.bytes = a.bytes + b.bytes; op.tag = a.tag + " x2";
-  return op;
-}
-
-static Program merge_pairs(Engine* e, const Program& a, const Program& b) {
-  Program out;
-  const size_t W = 8;      // how far one program may run ahead to re-align with the other
-  size_t i = 0, j = 0;
-  e->pair_launches = e->pair_singles = 0;
-  auto single = [&](const Op& o) { Op c = o; c.pd = nullptr; out.push_back(std::move(c)); ++e->pair_singles; };
-  while (i < a.size() && j < b.size()) {
-    if (can_pair(a[i], b[j])) { out.push_back(make_pair_op(e, a[i], b[j])); ++e->pair_launches; ++i; ++j; continue; }
-    size_t di = 0, dj = 0;
-    for (size_t k = 1; k <= W && i + k < a.size(); ++k) if (can_pair(a[i + k], b[j])) { di = k; break; }
-    for (size_t k = 1; k <= W && j + k < b.size(); ++k) if (can_pair(a[i], b[j + k])) { dj = k; break; }
-    if (dj && (!di || dj <= di)) { for (size_t k = 0; k < dj; ++k) single(b[j++]); }
-    else if (di) { for (size_t k = 0; k < di; ++k) single(a[i++]); }
-    else { single(a[i++]); single(b[j++]); }
-  }
-  while (i < a.size()) single(a[i++]);
-  while (j < b.size()) single(b[j++]);
-  return out;
-}
-
-// ------------------------------------------------------------------------------------------------
-// [conv / GEMM on a split-K plan] -> [GroupNorm small enough for the single-launch kernel] (every ResBlock at the 16x16 and 8x8
-// levels: `openaimodel.py:255-275`): the GroupNorm kernel reads the conv's fp32 partial slabs, applies the conv's epilogue with
-// the arithmetic of splitk_reduce_kernel, writes the conv's output tensor and normalises it from LDS.  Same bits, one launch
-// boundary (~3 us, serial chip-wide: DESIGN.md section 12) less per pair.
-// ------------------------------------------------------------------------------------------------
-static Program fuse_reduce_groupnorm(Engine* eng, const Program& prog, int* count) {
-  Program out;
-  for (size_t i = 0; i < prog.size(); ++i) {
-    const Op& a = prog[i];
-    if (i + 1 < prog.size() && a.pd && a.pd->kind == PairDesc::CONV && prog[i + 1].pd && prog[i + 1].pd->kind == PairDesc::GN) {
-      const ConvGemm& cg = a.pd->cg;
-      const GnArgs& gn = prog[i + 1].pd->gn;
-      if (cg.y && !cg.y32 && !cg.bias_per_row && !cg.ln_stats && !cg.stats_out && cg.act != 3 && gn.x == cg.y && gn.ldx == cg.ldy &&
-          gn.C == cg.N && gn.B * gn.HW == cg.M && cg.Ho * cg.Wo == gn.HW && cg.N % 8 == 0 && (!cg.res || cg.ldres % 8 == 0) &&
-          a.pd->sel == prog[i + 1].pd->sel && conv_gemm_plan_splitk(cg) > 1 && groupnorm_is_single_launch(gn)) {
-        std::shared_ptr<PairDesc> pa = a.pd, pg = prog[i + 1].pd;
-        Op op([eng, pa, pg](hipStream_t s) {
-          ConvGemm q = pa->cg;
-          q.workspace = pa->sel ? eng->splitk_ws2 : eng->splitk_ws;
-          q.workspace_bytes = eng->splitk_ws_bytes;
-          if (pa->scale_host) q.scale = *pa->scale_host;
-          q.no_reduce = 1;
-          if (int rc = conv_gemm(q, s)) return rc;
-          GnArgs g = pg->gn;
-          g.partials = pg->sel ? eng->gn_ws2 : eng->gn_ws;
-          g.red.ws = q.workspace; g.red.splitk = conv_gemm_plan_splitk(q);
-          g.red.bias = q.bias; g.red.bias2 = q.bias2; g.red.ld_bias2 = q.ld_bias2; g.red.res = q.res; g.red.ldres = q.ldres;
-          g.red.scale = q.scale; g.red.act = q.act; g.red.wscale = q.wscale;
-          return groupnorm_nhwc(g, s);
-        });
-        op.key = a.key; op.flops = a.flops; op.bytes = a.bytes + prog[i + 1].bytes; op.tag = a.tag + " +gn";
-        out.push_back(std::move(op));
-        ++*count;
-        ++i;
-        continue;
-      }
-    }
-    out.push_back(a);
-  }
-  return out;
 }
 
 static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* max_splitk, size_t* max_gn, std::string* err) {
@@ -1342,7 +1209,7 @@ static void free_configured(Engine* e) {
   if (e->arena2) (void)hipFree(e->arena2);
   e->arena2 = nullptr;
   for (Program* p : {&e->p_hint, &e->p_ctx_cn, &e->p_ctx_unet, &e->p_cn, &e->p_cn_export, &e->p_ctrl_import, &e->p_unet_enc,
-                     &e->p_unet_dec, &e->p_unet_noctrl, &e->p_vae, &e->p_pair, &e->f_cn, &e->f_unet_enc, &e->f_unet_dec, &e->f_unet_noctrl})
+                     &e->p_unet_dec, &e->p_unet_noctrl, &e->p_vae})
     p->clear();
 }
 
@@ -1370,8 +1237,6 @@ int sdeo_create(const sdeo_config* cfg, sdeo_handle* out) {
   e->hconvs = hint_convs(*cfg);
   if (const char* at = getenv("SDEO_AUTOTUNE")) e->autotune = atoi(at) != 0;
   if (const char* ov = getenv("SDEO_OVERLAP")) e->overlap = atoi(ov) != 0;
-  if (const char* pv = getenv("SDEO_PAIR")) e->pair = atoi(pv) != 0;
-  if (const char* fv = getenv("SDEO_FUSE_REDUCE_GN")) e->fuse_rg = atoi(fv) != 0;
   SDEO_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
   SDEO_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   SDEO_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
@@ -1563,15 +1428,6 @@ int sdeo_configure(sdeo_handle h, int n, int latent_h, int latent_w) {
     SDEO_CHECK(align_up(a.peak, 256) == h->arena_bytes && align_up(a2.peak, 256) == h->arena2_bytes,
                "sdeo_configure: arena plan not reproducible");
   }
-  h->p_pair = merge_pairs(h, h->p_unet_enc, h->p_cn);
-  h->fused_rg = 0;
-  h->f_cn = fuse_reduce_groupnorm(h, h->p_cn, &h->fused_rg);
-  h->f_unet_enc = fuse_reduce_groupnorm(h, h->p_unet_enc, &h->fused_rg);
-  h->f_unet_dec = fuse_reduce_groupnorm(h, h->p_unet_dec, &h->fused_rg);
-  { int dummy = 0; h->f_unet_noctrl = fuse_reduce_groupnorm(h, h->p_unet_noctrl, &dummy); }
-  if (getenv("SDEO_PAIR_REPORT"))
-    fprintf(stderr, "SDEO_PAIR: %zu + %zu launches -> %d shared + %d single\n", h->p_unet_enc.size(), h->p_cn.size(), h->pair_launches,
-            h->pair_singles);
   SDEO_HIP(hipDeviceSynchronize());      // autotune launches are done before the first real forward
   return 0;
 }
@@ -1614,7 +1470,7 @@ int sdeo_controlnet_forward(sdeo_handle h, const float* x_noisy, const float* hi
   SDEO_CHECK(!hint_new || hint, "sdeo_controlnet_forward: hint required");
   SDEO_CHECK(!ctx_new || context, "sdeo_controlnet_forward: context required");
   if (int rc = stage_inputs(h, x_noisy, hint, timesteps, ctx_new ? context : nullptr, hint_new, 2, s)) return rc;
-  if (int rc = run(h, h->fuse_rg ? h->f_cn : h->p_cn, s)) return rc;
+  if (int rc = run(h, h->p_cn, s)) return rc;
   if (int rc = run(h, h->p_cn_export, s)) return rc;
   for (size_t i = 0; i < h->ctrl_elems.size(); ++i)
     if (controls[i]) if (int rc = copy_in(controls[i], h->out_ctrl[i], h->ctrl_elems[i] * 4, s)) return rc;
@@ -1638,10 +1494,10 @@ int sdeo_unet_forward(sdeo_handle h, const float* x_noisy, const int64_t* timest
       if (int rc = copy_in(h->in_ctrl[i], controls[i], h->ctrl_elems[i] * 4, s)) return rc;
     }
     if (int rc = run(h, h->p_ctrl_import, s)) return rc;
-    if (int rc = run(h, h->fuse_rg ? h->f_unet_enc : h->p_unet_enc, s)) return rc;
-    if (int rc = run(h, h->fuse_rg ? h->f_unet_dec : h->p_unet_dec, s)) return rc;
+    if (int rc = run(h, h->p_unet_enc, s)) return rc;
+    if (int rc = run(h, h->p_unet_dec, s)) return rc;
   } else {
-    if (int rc = run(h, h->fuse_rg ? h->f_unet_noctrl : h->p_unet_noctrl, s)) return rc;
+    if (int rc = run(h, h->p_unet_noctrl, s)) return rc;
   }
   return copy_in(eps, h->out_eps, (size_t)h->N * h->cfg.out_channels * h->lh * h->lw * 4, s);
 }
@@ -1660,23 +1516,21 @@ int sdeo_apply_model(sdeo_handle h, const float* x_noisy, const float* hint, con
   h->only_mid = only_mid_control;
   for (int i = 0; i < 13; ++i) h->scales[i] = host_control_scales ? host_control_scales[i] : 1.0f;
   if (no_control) {
-    if (int rc = run(h, h->fuse_rg ? h->f_unet_noctrl : h->p_unet_noctrl, s)) return rc;
+    if (int rc = run(h, h->p_unet_noctrl, s)) return rc;
   } else {
-    if (h->pair) {
-      if (int rc = run(h, h->p_pair, s)) return rc;
-    } else if (h->overlap && !h->profiling) {
+    if (h->overlap && !h->profiling) {
       // fork: ControlNet on the side stream, UNet encoder + middle block on the caller's stream (capturable)
       SDEO_HIP(hipEventRecord(h->ev_fork, s));
       SDEO_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-      if (int rc = run(h, h->fuse_rg ? h->f_cn : h->p_cn, h->side)) return rc;
+      if (int rc = run(h, h->p_cn, h->side)) return rc;
       SDEO_HIP(hipEventRecord(h->ev_join, h->side));
-      if (int rc = run(h, h->fuse_rg ? h->f_unet_enc : h->p_unet_enc, s)) return rc;
+      if (int rc = run(h, h->p_unet_enc, s)) return rc;
       SDEO_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
     } else {
-      if (int rc = run(h, h->fuse_rg ? h->f_cn : h->p_cn, s)) return rc;
-      if (int rc = run(h, h->fuse_rg ? h->f_unet_enc : h->p_unet_enc, s)) return rc;
+      if (int rc = run(h, h->p_cn, s)) return rc;
+      if (int rc = run(h, h->p_unet_enc, s)) return rc;
     }
-    if (int rc = run(h, h->fuse_rg ? h->f_unet_dec : h->p_unet_dec, s)) return rc;
+    if (int rc = run(h, h->p_unet_dec, s)) return rc;
   }
   return copy_in(eps, h->out_eps, (size_t)h->N * h->cfg.out_channels * h->lh * h->lw * 4, s);
 }
@@ -1699,24 +1553,6 @@ int sdeo_vae_decode(sdeo_handle h, const float* z, int n, float* images, uint8_t
 }
 
 size_t sdeo_device_bytes(sdeo_handle h) { return h ? h->device_bytes : 0; }
-
-// tests / A-B measurements: switch the paired ControlNet + UNet-encoder program on or off, report its launch counts
-int sdeo_debug_set_pair(sdeo_handle h, int on) {
-  SDEO_CHECK(h, "null handle");
-  h->pair = on != 0;
-  return 0;
-}
-int sdeo_debug_set_reduce_gn(sdeo_handle h, int on) {
-  SDEO_CHECK(h, "null handle");
-  h->fuse_rg = on != 0;
-  return 0;
-}
-int sdeo_debug_reduce_gn_count(sdeo_handle h) { return h ? h->fused_rg : -1; }
-int sdeo_debug_pair_counts(sdeo_handle h, int* shared, int* single) {
-  SDEO_CHECK(h && shared && single, "null argument");
-  *shared = h->pair_launches; *single = h->pair_singles;
-  return 0;
-}
 
 int sdeo_profile_begin(sdeo_handle h) {
   SDEO_CHECK(h, "sdeo_profile_begin: null handle");

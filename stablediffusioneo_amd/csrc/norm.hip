@@ -17,19 +17,11 @@ namespace sdeo {
 // statistics chunks per image: enough blocks to fill 256 CUs at the 64x64 level, capped so the
 // second-level sum stays short
 // upper bound of the statistics chunks per image (sizes the partial-sum workspace)
-// operands of one GroupNorm problem; a launch takes one or two problems of the same shape (pair launch, see KP2 in conv_inl.h):
-// batch entries >= Bper belong to the second
+// operands of one GroupNorm problem
 struct GnOne {
   f16* y; const f16* x; const float* gamma; const float* beta; float* partials; int ldy, ldx;
-  // single-launch kernel only: x arrives as split-K slabs (GnReduce in kernels.h); N = C, rows = B * HW
-  const float* ws; const float* rbias; const float* rbias2; const f16* rres; const float* rwscale;
-  int splitk, ld_bias2, ldres, act, rows, N;
-  float scale;
 };
-#ifndef SDEO_PAIR_SLOTS
-#define SDEO_PAIR_SLOTS 2
-#endif
-struct GnPair { GnOne k[SDEO_PAIR_SLOTS]; };
+struct GnPair { GnOne k[1]; };
 
 int gn_chunks(int HW) { const int c = cdiv(HW, 8); return c > 128 ? 128 : (c < 1 ? 1 : c); }
 
@@ -51,7 +43,7 @@ static int gn_vec_per_block(int C, int groups) {
 // fixed 8-channel vector cv, so a wave reads whole contiguous NHWC rows.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnPair gp, int Bper, int HW, int C, int cpg, int nvb, int nchunks,
                                                        int groups, int ppc) {
-  const GnOne& g1 = gp.k[(int)blockIdx.z >= Bper];
+  const GnOne& g1 = gp.k[0];
   const f16* __restrict__ x = g1.x;
   const int ldx = g1.ldx;
   float* __restrict__ partials = g1.partials;
@@ -60,7 +52,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnPair gp, int Bper
   const int tid = threadIdx.x;
   const int P = 256 / nvb;
   const int cv = tid % nvb, prow = tid / nvb;
-  const int chunk = blockIdx.x, part = blockIdx.y, b = (int)blockIdx.z >= Bper ? blockIdx.z - Bper : blockIdx.z;
+  const int chunk = blockIdx.x, part = blockIdx.y, b = blockIdx.z;
   const int c0 = (part * nvb + cv) * 8;
   const int pbeg = chunk * ppc;
   const int pend = min(HW, pbeg + ppc);
@@ -140,7 +132,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnPair gp, int Bper
 // grid: (chunks, channel-parts, B): fold mean/rstd/gamma/beta into per-channel a,b in LDS, then y = x*a+b.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnPair gp, int Bper, int HW, int C, int cpg, int nvb,
                                                        int nchunks, int groups, float eps, int with_silu, int ppc, int nsc) {
-  const GnOne& g1 = gp.k[(int)blockIdx.z >= Bper];
+  const GnOne& g1 = gp.k[0];
   f16* __restrict__ y = g1.y;
   const f16* __restrict__ x = g1.x;
   const int ldy = g1.ldy, ldx = g1.ldx;
@@ -154,7 +146,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnPair gp, int Bper
   const int tid = threadIdx.x;
   const int P = 256 / nvb;
   const int cv = tid % nvb, prow = tid / nvb;
-  const int chunk = blockIdx.x, part = blockIdx.y, b = (int)blockIdx.z >= Bper ? blockIdx.z - Bper : blockIdx.z;
+  const int chunk = blockIdx.x, part = blockIdx.y, b = blockIdx.z;
   const int gpb = nvb * 8 / cpg;
   const bool active = prow < P;
   const int c0 = (part * nvb + cv) * 8;
@@ -281,7 +273,7 @@ __global__ __launch_bounds__(256) void gn_fold_partials_kernel(float2* __restric
 template <int NT>
 __global__ __launch_bounds__(NT) void gn_fused_kernel(const GnPair gp, int Bper, int HW, int cpg, int nvw, int nsweep, float eps,
                                                       int with_silu) {
-  const GnOne& g1 = gp.k[(int)blockIdx.y >= Bper];
+  const GnOne& g1 = gp.k[0];
   f16* __restrict__ y = g1.y;
   const f16* __restrict__ x = g1.x;
   const int ldy = g1.ldy, ldx = g1.ldx;
@@ -293,7 +285,7 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const GnPair gp, int Bper,
   const int P = NT / nvw;                       // pixel rows per sweep
   const int v = tid % nvw, prow = tid / nvw;
   const bool active = prow < P;
-  const int part = blockIdx.x, b = (int)blockIdx.y >= Bper ? blockIdx.y - Bper : blockIdx.y;
+  const int part = blockIdx.x, b = blockIdx.y;
   const int c0 = (part * nvw + v) * 8;          // parts start on a group boundary
   char* slice = gsm;                                                                  // [nsweep][NT] 16-byte vectors
   float2* part_sq = reinterpret_cast<float2*>(gsm + (size_t)nsweep * NT * 16);        // [2 * nvw][P]
@@ -303,57 +295,7 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const GnPair gp, int Bper,
 
   const f16* xb = x + ((size_t)b * HW) * ldx + c0;
   f16* yb = y + ((size_t)b * HW) * ldy + c0;
-  if (g1.ws) {
-    // x = the not-yet-reduced output of a split-K conv: sum the slabs and apply that conv's epilogue exactly as
-    // splitk_reduce_kernel does (same order of additions, same single rounding), keep the fp16 vector in LDS and write it to x
-    const size_t zs = (size_t)g1.rows * g1.N;
-    f32x4 bv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, b2[2] = {bv[0], bv[0]}, wsv[2] = {bv[0], bv[0]};
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      if (g1.rbias) bv[hh] = *reinterpret_cast<const f32x4*>(g1.rbias + c0 + 4 * hh);
-      if (g1.rbias2) b2[hh] = *reinterpret_cast<const f32x4*>(g1.rbias2 + (size_t)b * g1.ld_bias2 + c0 + 4 * hh);
-      if (g1.rwscale) wsv[hh] = *reinterpret_cast<const f32x4*>(g1.rwscale + c0 + 4 * hh);
-    }
-    for (int k = 0; k < nsweep; ++k) {
-      const int pix = prow + k * P;
-      f16x8 o = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (active && pix < HW) {
-        const size_t m = (size_t)b * HW + pix;
-        f16x8 rv = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (g1.rres) rv = *reinterpret_cast<const f16x8*>(g1.rres + m * g1.ldres + c0);
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const float* src = g1.ws + m * g1.N + c0 + 4 * hh;
-          f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-          for (int z0 = 0; z0 < g1.splitk; z0 += 8) {
-            f32x4 t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-              t[u] = (z0 + u < g1.splitk) ? *reinterpret_cast<const f32x4*>(src + (size_t)(z0 + u) * zs) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v += t[u];
-          }
-          if (g1.rwscale) v *= wsv[hh];
-          v += bv[hh];
-          v += b2[hh];
-          if (g1.act == 1) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] = silu_f(v[t]);
-          } else if (g1.act == 2) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] = quick_gelu_f(v[t]);
-          }
-          v *= g1.scale;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) v[t] += (float)rv[4 * hh + t];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) o[4 * hh + t] = (f16)v[t];
-        }
-        *reinterpret_cast<f16x8*>(const_cast<f16*>(xb) + (size_t)pix * ldx) = o;
-      }
-      *reinterpret_cast<f16x8*>(slice + (size_t)k * NT * 16 + (size_t)tid * 16) = o;
-    }
-  } else {
+  {
     for (int k = 0; k < nsweep; ++k) {
       const int pix = prow + k * P;
       // lanes without a pixel fetch a valid dummy (the first pixel of their vector); they are masked below
@@ -472,11 +414,11 @@ static size_t gn_fused_smem(int HW, int nvw) {
 
 template <int NT>
 static int launch_gn_fused(const GnPair& gp, int count, int B, int HW, int C, int cpg, int nvw, float eps, int with_silu, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_done;
+  if (attr_done.need()) {
     SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)kGnFusedLdsCap));
-    attr_done = true;
+    attr_done.mark();
   }
   const int P = NT / nvw, nsweep = cdiv(HW, P);
   hipLaunchKernelGGL((gn_fused_kernel<NT>), dim3((C / 8) / nvw, B * count), dim3(NT), gn_fused_smem<NT>(HW, nvw), stream, gp, B, HW,
@@ -490,9 +432,6 @@ static int gn_check(const GnArgs& a) {
   SDEO_CHECK(a.B > 0 && a.HW > 0 && a.C > 0, "groupnorm: empty tensor");
   SDEO_CHECK(a.groups > 0 && a.groups <= 64 && a.C % a.groups == 0, "groupnorm: C=%d not divisible into %d groups", a.C, a.groups);
   SDEO_CHECK(a.C % 8 == 0 && a.ldx % 8 == 0 && a.ldy % 8 == 0, "groupnorm: C=%d ldx=%d ldy=%d must be multiples of 8", a.C, a.ldx, a.ldy);
-  if (a.red.ws)
-    SDEO_CHECK(a.red.splitk >= 2 && (!a.red.res || a.red.ldres % 8 == 0) && a.red.act >= 0 && a.red.act <= 2,
-               "groupnorm: bad split-K input (splitk %d, ldres %d, act %d)", a.red.splitk, a.red.ldres, a.red.act);
   return 0;
 }
 
@@ -523,7 +462,7 @@ static int gn_dispatch(const GnArgs& a, const GnPair& gp, int count, hipStream_t
   const int cpg = C / groups;
   if (a.ext_partials) {
     // statistics came out of the producer's epilogue: normalise only
-    SDEO_CHECK(count == 1 && !a.red.ws && a.ext_nsc >= 1, "groupnorm: producer partials go with a single, plain problem");
+    SDEO_CHECK(count == 1 && a.ext_nsc >= 1, "groupnorm: bad producer partials");
     const int nvb = gn_vec_per_block(C, groups);
     SDEO_CHECK(nvb > 0, "groupnorm: unsupported channel split C=%d groups=%d", C, groups);
     const int parts = (C / 8) / nvb, P = 256 / nvb;
@@ -537,7 +476,7 @@ static int gn_dispatch(const GnArgs& a, const GnPair& gp, int count, hipStream_t
                          reinterpret_cast<const float2*>(a.ext_partials), nsc, groups);
       nsc = 1;
     } else {
-      for (int i = 0; i < SDEO_PAIR_SLOTS; ++i) g2.k[i].partials = const_cast<float*>(a.ext_partials);
+      g2.k[0].partials = const_cast<float*>(a.ext_partials);
     }
     hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks, parts, B), dim3(256), 0, stream, g2, B, HW, C, cpg, nvb, chunks, groups, eps, with_silu, ppc, nsc);
     SDEO_HIP(hipGetLastError());
@@ -549,7 +488,6 @@ static int gn_dispatch(const GnArgs& a, const GnPair& gp, int count, hipStream_t
     if (nt == 256) return launch_gn_fused<256>(gp, count, B, HW, C, cpg, nvw, eps, with_silu, stream);
     if (nt == 1024) return launch_gn_fused<1024>(gp, count, B, HW, C, cpg, nvw, eps, with_silu, stream);
   }
-  SDEO_CHECK(!a.red.ws, "groupnorm: split-K slabs as input need the single-launch kernel (HW=%d C=%d)", HW, C);
   const int nvb = gn_vec_per_block(C, groups);
   SDEO_CHECK(nvb > 0, "groupnorm: unsupported channel split C=%d groups=%d", C, groups);
   const int parts = (C / 8) / nvb;
@@ -571,33 +509,13 @@ static int gn_dispatch(const GnArgs& a, const GnPair& gp, int count, hipStream_t
   return 0;
 }
 
-static GnOne gn_one(const GnArgs& a) {
-  return GnOne{a.y, a.x, a.gamma, a.beta, a.partials, a.ldy, a.ldx, a.red.ws, a.red.bias, a.red.bias2, a.red.res, a.red.wscale,
-               a.red.splitk, a.red.ld_bias2, a.red.ldres, a.red.act, a.B * a.HW, a.C, a.red.scale};
-}
+static GnOne gn_one(const GnArgs& a) { return GnOne{a.y, a.x, a.gamma, a.beta, a.partials, a.ldy, a.ldx}; }
 
 int groupnorm_nhwc(const GnArgs& a, hipStream_t stream) {
   if (int rc = gn_check(a)) return rc;
   GnPair gp{};
-  gp.k[0] = gp.k[SDEO_PAIR_SLOTS - 1] = gn_one(a);
-  return gn_dispatch(a, gp, 1, stream);
-}
-
-bool groupnorm_can_pair(const GnArgs& a, const GnArgs& b) {
-  return SDEO_PAIR_SLOTS == 2 && !a.red.ws && !b.red.ws && a.B == b.B && a.HW == b.HW && a.C == b.C && a.groups == b.groups && a.eps == b.eps && a.with_silu == b.with_silu;
-}
-
-int groupnorm_nhwc_pair(const GnArgs& a, const GnArgs& b, hipStream_t stream) {
-  if (!groupnorm_can_pair(a, b) || a.partials == b.partials) {
-    if (int rc = groupnorm_nhwc(a, stream)) return rc;
-    return groupnorm_nhwc(b, stream);
-  }
-  if (int rc = gn_check(a)) return rc;
-  if (int rc = gn_check(b)) return rc;
-  GnPair gp{};
   gp.k[0] = gn_one(a);
-  gp.k[SDEO_PAIR_SLOTS - 1] = gn_one(b);
-  return gn_dispatch(a, gp, 2, stream);
+  return gn_dispatch(a, gp, 1, stream);
 }
 
 int groupnorm_nhwc(f16* y, int ldy, const f16* x, int ldx, const float* gamma, const float* beta, int B, int HW, int C,

@@ -46,16 +46,6 @@ int sdeo_debug_conv2d_gn_f16(void* ynorm, void* y, const void* x, const void* w_
 int sdeo_debug_quantize_fp8_rows(void* w_f16_inout, void* q_out, float* scale_out, int rows, int cols, void* stream);
 void sdeo_debug_next_weights_fp8(const void* q, const float* scale);
 
-/* pair launches (csrc/net.hip merge_pairs): ControlNet and UNet encoder zipped into one program whose same-shaped ops share a
- * launch; `on` = 0 restores the two-program schedule (same bits either way).  counts: launches of the merged program that carry
- * two problems / one problem (valid after sdeo_configure). */
-int sdeo_debug_set_pair(sdeo_handle h, int on);
-/* split-K reduce fused into the following single-launch GroupNorm (csrc/net.hip fuse_reduce_groupnorm): off by default (measured
- * neutral); `on` = 1 runs the fused programs (same bits); count = fused pairs per apply_model pass (valid after sdeo_configure) */
-int sdeo_debug_set_reduce_gn(sdeo_handle h, int on);
-int sdeo_debug_reduce_gn_count(sdeo_handle h);
-int sdeo_debug_pair_counts(sdeo_handle h, int* shared, int* single);
-
 #ifdef __cplusplus
 }
 #endif

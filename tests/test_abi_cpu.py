@@ -21,7 +21,7 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.sdeo_version() >= 100
+    assert lib.sdeo_version() == 101          # include/sdeo.h SDEO_ABI_VERSION; _lib.load() refuses a library that disagrees with the header
     assert isinstance(lib.sdeo_last_error(), bytes)
 
 

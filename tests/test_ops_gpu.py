@@ -139,7 +139,31 @@ def test_conv2d_epilogue(ops):
     assert_close(y.permute(0, 3, 1, 2), ref, rtol=2e-3, atol=3e-3, what="conv epilogue")
 
 
-DMA_TILES = [0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 19, 20, 21, 26, 27, 28, 29, 30, 31, 32, 33]     # kTiles indices of conv_gemm_dma_kernel<BM,BN,STAGES> in csrc/conv_gemm.hip
+DMA_TILES = [0, 1, 2, 5, 6, 7, 8, 9, 10, 11, 12, 19, 20, 21, 26, 27, 28, 29, 30, 31, 32, 33,      # kTiles indices of conv_gemm_dma_kernel<BM,BN,STAGES> in csrc/conv_gemm.hip
+             41, 42, 43, 44, 45, 46, 47, 48]                                                        # ... <BM,BN,STAGES,KPB>: one barrier per group of KPB K-steps
+GROUPED_TILES = [41, 42, 43, 44, 45, 46, 47, 48]
+
+
+@pytest.mark.parametrize("tile", GROUPED_TILES)
+def test_gemm_grouped_barrier_tiles_every_k(ops, tile):
+    """conv_gemm_dma_kernel<..., KPB>: K of 1 .. 41 steps (fewer steps than the prologue fills, partial last groups, one group only),
+    with split-K, residual and bias, ragged M and N"""
+    import ctypes as C
+    from stablediffusioneo_amd import _lib
+    lib = _lib.load()
+    try:
+        for sk in (1, 2):
+            lib.sdeo_debug_force_gemm_plan(C.c_int(tile), C.c_int(sk))
+            for (m, n, k) in [(200, 328, 64), (128, 160, 128), (333, 320, 192), (256, 640, 320), (512, 72, 448), (130, 1280, 640), (96, 200, 2624)]:
+                x = h16(randn((m, k), 260 + k)).to(DEV)
+                w = h16(randn((n, k), 261) * k ** -0.5).to(DEV)
+                bias = (0.1 * randn((n,), 262)).to(DEV)
+                res = h16(randn((m, n), 263)).to(DEV)
+                y = ops.gemm(x, w, bias=bias, res=res)
+                ref = x.float() @ w.float().t() + bias + res.float()
+                assert_close(y, ref, rtol=2e-3, atol=3e-3, what=f"grouped tile {tile} sk {sk} gemm {(m, n, k)}")
+    finally:
+        lib.sdeo_debug_force_gemm_plan(C.c_int(-1), C.c_int(0))
 
 
 @pytest.mark.parametrize("tile", DMA_TILES)
@@ -165,7 +189,10 @@ def test_conv2d_every_dma_tile(ops, tile, sk):
 
 
 HALO_TILES = {13: (8, 16, 80, 4), 14: (8, 16, 160, 4), 15: (8, 8, 80, 4), 16: (8, 8, 160, 4), 17: (8, 16, 64, 4), 18: (8, 16, 128, 4),
-              22: (8, 16, 80, 8), 23: (8, 16, 160, 8), 24: (8, 16, 64, 8), 25: (8, 16, 128, 8)}   # kTiles index -> (PH, PW, BN, MFMA waves)
+              22: (8, 16, 80, 8), 23: (8, 16, 160, 8), 24: (8, 16, 64, 8), 25: (8, 16, 128, 8),
+              # one barrier per filter row (three taps per ring slot)
+              34: (8, 16, 80, 4, 3), 35: (8, 16, 80, 8, 3), 36: (8, 16, 64, 4, 3), 37: (8, 8, 80, 4, 3), 38: (8, 8, 160, 4, 3),
+              39: (8, 16, 128, 8, 3), 40: (8, 16, 64, 8, 3)}   # kTiles index -> (PH, PW, BN, MFMA waves[, taps per barrier])
 
 
 @pytest.mark.parametrize("tile", sorted(HALO_TILES))
@@ -178,13 +205,14 @@ def test_conv2d_every_halo_tile(ops, tile, sk):
     from stablediffusioneo_amd import _lib
     lib = _lib.load()
     lib.sdeo_debug_conv2d_kernel_name.restype = C.c_char_p
-    ph, pw, bn, nmw = HALO_TILES[tile]
+    ph, pw, bn, nmw = HALO_TILES[tile][:4]
+    kname = "conv3x3_halo_kernel<" + ",".join(str(v) for v in HALO_TILES[tile]) + ">"
     try:
         lib.sdeo_debug_force_gemm_plan(C.c_int(tile), C.c_int(sk))
         for (n, cin, h, w, cout) in [(2, 320, 2 * ph, 2 * pw, 320), (1, 64, ph, pw, 72), (2, 128, 3 * ph, pw, 164), (1, 192, ph, 3 * pw, 640)]:
             name = lib.sdeo_debug_conv2d_kernel_name(C.c_int(n), C.c_int(h), C.c_int(w), C.c_int(cin), C.c_int(cout), C.c_int(3),
                                                      C.c_int(1), C.c_int(0)).decode()
-            assert name == f"conv3x3_halo_kernel<{ph},{pw},{bn},{nmw}>", name
+            assert name == kname, name
             x = h16(randn((n, cin, h, w), 240 + cin))
             wt = h16(randn((cout, cin, 3, 3), 241) * (1.0 / (cin * 9)) ** 0.5)
             bias = 0.1 * randn((cout,), 242)
@@ -454,3 +482,31 @@ def test_layout_roundtrip(ops):
     assert y.shape == (2, 6, 10, 8) and float(y[..., 4:].abs().max()) == 0.0
     z = ops.nhwc_to_nchw_f32(y, 4)
     assert torch.equal(z.cpu(), x.half().float())
+
+
+def test_reference_attention_vectors_through_hip(ops):
+    """The vectors of the reference's one runnable test (`ldm_torch/modules/test_attention_onnx_torch_error.py:173-200`: CrossAttention
+    with x (2, 10, 512), context (2, 10, 77), 8 heads of 64, its own seeded weights; stored by tests/golden/make_golden.py as
+    attention_test.npz) through the HIP chain the networks run for `attention.py:227-249`: to_q / to_k / to_v GEMMs (the 77-wide context
+    zero-padded to 80 columns: Cin % 8), flash attention over the 10 keys (rows padded to 16 and masked), to_out + bias.  The reference
+    checks its fused variant against the original at atol 1e-6 in fp32; here the operands are rounded to fp16, so the bound is the fp16
+    one of this file (2e-3 relative + 3e-3)."""
+    g = np.load(os.path.join(GOLDEN, "attention_test.npz"))
+    x = torch.tensor(g["x"])
+    ctx = torch.tensor(g["context"])
+    B, T, C = x.shape
+    Tc, Cc = ctx.shape[1], ctx.shape[2]
+    heads = 8
+    pad = lambda t, n: torch.cat([t, torch.zeros(*t.shape[:-1], n - t.shape[-1])], -1)
+    wq, wk, wv = torch.tensor(g["sd.to_q.weight"]), pad(torch.tensor(g["sd.to_k.weight"]), 80), pad(torch.tensor(g["sd.to_v.weight"]), 80)
+    wo, bo = torch.tensor(g["sd.to_out.0.weight"]), torch.tensor(g["sd.to_out.0.bias"])
+    TkS = 16
+    ctxp = torch.zeros(B, TkS, 80)
+    ctxp[:, :Tc, :Cc] = ctx
+    q = ops.gemm(h16(x.reshape(B * T, C)).to(DEV), h16(wq).to(DEV)).reshape(B, T, C)
+    k = ops.gemm(h16(ctxp.reshape(B * TkS, 80)).to(DEV), h16(wk).to(DEV)).reshape(B, TkS, C)
+    v = ops.gemm(h16(ctxp.reshape(B * TkS, 80)).to(DEV), h16(wv).to(DEV)).reshape(B, TkS, C)
+    o = ops.attention(q.contiguous(), k.contiguous(), v.contiguous(), heads, tk=Tc)
+    y = ops.gemm(o.reshape(B * T, C), h16(wo).to(DEV), bias=bo.to(DEV)).reshape(B, T, C)
+    for name in ("out_original", "out_fused_class"):
+        assert_close(y, torch.tensor(g[name]), rtol=2e-3, atol=3e-3, what=f"reference CrossAttention vectors ({name})")

@@ -48,8 +48,8 @@ def cold_us(fn, reps=7):
 GEMMS = [(8192, 320, 320), (8192, 320, 1280), (2048, 640, 640), (2048, 640, 2560), (512, 1280, 1280), (512, 1280, 5120), (128, 1280, 1280),
          (8192, 960, 320), (2048, 1920, 640), (512, 3840, 1280)]
 CONVS = [(2, 8, 8, 1280, 1280), (2, 16, 16, 1280, 1280), (2, 64, 64, 320, 320), (2, 32, 32, 640, 640)]
-DMA = [0, 1, 2, 5, 6, 7, 9, 10, 11, 12, 19, 20, 21, 26, 27, 28, 29, 30, 31, 32, 33]
-HALO = [13, 14, 15, 16, 22, 23]
+DMA = [0, 1, 2, 5, 6, 7, 9, 10, 11, 12, 19, 20, 21, 26, 27, 28, 29, 30, 31, 32, 33, 41, 42, 43, 44, 45, 46, 47, 48]
+HALO = [13, 14, 15, 16, 22, 23, 34, 35, 37, 38]
 name = lib.sdeo_debug_conv2d_kernel_name
 name.restype = C.c_char_p
 
@@ -72,7 +72,7 @@ def run(label, fn, tiles, sks):
     base = [r for r in rows if r[2] < 0][0]
     rows.sort()
     print(f"  tuned plan: cold {base[0]:.1f} us  hot {base[1]:.1f} us")
-    for c, h, tile, sk in rows[:6]:
+    for c, h, tile, sk in rows[:8]:
         print(f"  tile {tile:3d} sk {sk:2d}: cold {c:6.1f} us   hot {h:6.1f} us")
     sys.stdout.flush()
 

@@ -1,11 +1,11 @@
 #!/bin/bash
-# (re-)measure GEMM plans (tools/tune_plans.py; SDEO_TUNED_PLANS=0 in the environment = every shape, not just the missing ones),
-# install the table, then the op-level tile tests and two bench lines
+# (re-)measure the conv / GEMM plan table on the MI355X (tools/tune_plans.py; SDEO_TUNED_PLANS=0 = every shape), install it for the
+# rest of this call, then two bench lines.  Copy gpurun_out/<tag>/tuned_plans_gfx950.json over the committed table afterwards.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/r2tune
+OUT=$R/gpurun_out/${1:-tune}
 mkdir -p $OUT
 cd $R
-timeout -k 10 1050 python tools/tune_plans.py > $OUT/tune.log 2>&1; rc=$?; tail -3 $OUT/tune.log; echo "tune rc=$rc"
+timeout -k 10 1080 python tools/tune_plans.py > $OUT/tune.log 2>&1; rc=$?; tail -3 $OUT/tune.log; echo "tune rc=$rc"
 [ $rc -ne 0 ] && exit $rc
 cp $R/gpurun_out/tuned_plans_gfx950.json $R/stablediffusioneo_amd/tuned_plans_gfx950.json && cp $R/gpurun_out/tuned_plans_gfx950.json $OUT/
 for i in 1 2; do

@@ -37,9 +37,10 @@ def graph_us(fn, n=20):
     return best
 
 
-SHAPES = [(2, 32, 32, 640, 640), (2, 32, 32, 320, 640), (2, 32, 32, 1280, 640), (2, 32, 32, 960, 640), (2, 64, 64, 320, 320),
-          (2, 64, 64, 640, 320), (2, 16, 16, 1280, 1280), (2, 16, 16, 640, 1280)]
-CANDS = [(-1, 0), (13, 1), (22, 1), (15, 1), (16, 1), (14, 1), (23, 1), (6, 1), (7, 1), (9, 1), (13, 2), (22, 2), (15, 2)]
+SHAPES = [(2, 64, 64, 320, 320), (2, 64, 64, 640, 320), (2, 32, 32, 640, 640), (2, 32, 32, 1280, 640), (2, 16, 16, 1280, 1280), (2, 8, 8, 1280, 1280),
+          (1, 512, 512, 128, 128), (1, 256, 256, 256, 256)]
+CANDS = [(-1, 0), (13, 1), (34, 1), (22, 1), (35, 1), (15, 1), (37, 1), (16, 1), (38, 1), (17, 1), (36, 1), (24, 1), (40, 1), (13, 2), (34, 2), (22, 2), (35, 2), (15, 2), (37, 2),
+         (13, 4), (34, 4), (37, 4), (15, 4), (15, 8), (37, 8)]
 if len(sys.argv) > 1:
     SHAPES = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
 
