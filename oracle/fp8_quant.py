@@ -32,6 +32,25 @@ def quantize_rows(w: torch.Tensor):
     return codes, scale, codes.view(torch.float8_e4m3fn).float() * scale[:, None]
 
 
+def quantize_mx(x: torch.Tensor):
+    """Block-scaled fp8 pack (csrc/elementwise.hip quantize_mx_kernel): x [rows][cols] (values on the fp16 grid), cols % 32 == 0 ->
+    (codes uint8 [rows][cols], e8m0 scale bytes uint8 [rows][cols / 32], dequantised f32).  Per block of 32 consecutive elements of a
+    row: scale = 2^e, the smallest power of two with max|x| / scale <= 448 (e = 0 for an all-zero block), stored as e + 127; codes =
+    e4m3fn(x / scale), round to nearest even (torch's cast).  The MFMA (v_mfma_scale_f32_16x16x128_f8f6f4) multiplies the decoded
+    codes and the two block scales exactly and accumulates in fp32."""
+    rows, cols = x.shape
+    assert cols % 32 == 0
+    b = x.float().reshape(rows, cols // 32, 32)
+    amax = b.abs().amax(dim=2)
+    m, ex = torch.frexp(amax)
+    e = torch.where(amax > 0, torch.where(m <= 0.875, ex - 9, ex - 8), torch.zeros_like(ex))
+    scale = torch.ldexp(torch.ones_like(amax), e)
+    q = (b / scale[:, :, None]).to(torch.float8_e4m3fn)
+    codes = q.view(torch.uint8).reshape(rows, cols).clone()
+    deq = (q.float() * scale[:, :, None]).reshape(rows, cols)
+    return codes, (e + 127).to(torch.uint8), deq
+
+
 def _q2d(w: torch.Tensor) -> torch.Tensor:
     """quantise a Linear [out][in] or conv [out][in][kh][kw] weight per output channel (library layout: [out][kh][kw][in])"""
     w16 = w.to(torch.float16).float()

@@ -175,6 +175,22 @@ int sdeo_gemm_f16(void* y, int ldy, const void* x, int ldx, const void* w, int l
   return conv_gemm(p, S(stream));
 }
 
+// block-scaled fp8 ("MX") at op level: pack an fp16 matrix, and the GEMM on two packed operands (v_mfma_scale_f32_16x16x128_f8f6f4)
+int sdeo_debug_quantize_mx(void* q_out, void* scales_out, const void* x, int rows, int cols, void* stream) {
+  return quantize_mx((uint8_t*)q_out, (uint8_t*)scales_out, (const f16*)x, rows, cols, cols, cols, cols / 32, S(stream));
+}
+int sdeo_debug_gemm_mx_f16(void* y, int ldy, const void* xq, const void* xs, const void* wq, const void* ws, const float* bias, const void* res,
+                           int ldres, int m, int n, int k, int act, void* workspace, size_t workspace_bytes, void* stream) {
+  (void)disarm_fp8();
+  ConvGemm p;
+  fill_gemm(p, m, n, k);
+  p.x = (const f16*)xq; p.w = (const f16*)wq; p.y = (f16*)y; p.bias = bias; p.res = (const f16*)res;
+  p.ldx = k; p.ldw = k; p.ldy = ldy; p.ldres = ldres; p.act = act;
+  p.mx_sx = (const uint8_t*)xs; p.mx_sw = (const uint8_t*)ws; p.mx_ldsx = k / 32; p.mx_ldsw = k / 32;
+  p.workspace = (float*)workspace; p.workspace_bytes = workspace_bytes;
+  return conv_gemm(p, S(stream));
+}
+
 int sdeo_debug_quantize_fp8_rows(void* w_f16_inout, void* q_out, float* scale_out, int rows, int cols, void* stream) {
   return quantize_fp8_rows((uint8_t*)q_out, scale_out, (f16*)w_f16_inout, rows, cols, cols, cols, S(stream));
 }

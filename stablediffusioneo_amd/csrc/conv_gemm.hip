@@ -52,9 +52,14 @@ namespace sdeo {
 // then refill the KPB slots of the previous group.  A small tile has 10 - 20 MFMAs per wave per step (160 - 320 clocks) against a
 // barrier / wait skeleton of ~240 clocks per step; the halo kernel gained 14 - 35 % from the same change
 // (conv_halo.hip TPB).  Needs STAGES >= 2 KPB; STAGES - 2 KPB steps of loads stay in flight across a barrier.
-template <int BM, int BN, int STAGES, bool UPS, bool WS, bool W8 = false, int KPB = 1>
+// MX: both operands are block-scaled fp8 (KP::mx_sx): the loaders move the same 128-byte rows (128 codes instead of 64 halves: the
+// address arithmetic is that of an fp16 problem of half the length), the MFMA waves read each lane's 32 consecutive codes as two
+// 16-byte chunks and issue v_mfma_scale_f32_16x16x128_f8f6f4 with the two e8m0 block scales of the lane's row and 32-code block:
+// 4x the K per MFMA at twice its cycles, half the operand bytes per FLOP.  GEMM (1x1) only, wave-specialised only.
+template <int BM, int BN, int STAGES, bool UPS, bool WS, bool W8 = false, int KPB = 1, bool MX = false>
 __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2 pp) {
   const KP& p = pp.k[blockIdx.y];
+  static_assert(!MX || (WS && !W8 && !UPS && KPB == 1), "the block-scaled fp8 path exists for the plain wave-specialised GEMM");
   constexpr int BK = 64, RPP = 32;
   constexpr int WRPP = W8 ? 64 : 32;                           // weight rows per DMA pass
   constexpr int XP = BM / RPP, WP = (BN + WRPP - 1) / WRPP, L = XP + WP;     // DMA instructions per loading thread per stage
@@ -346,7 +351,86 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
       // retire every scalar (kernel-argument) load here: while one may be pending the compiler's wait-count pass has to
       // assume out-of-order LGKM returns and turns each partial lgkmcnt(N) in the loop into lgkmcnt(0)
       __builtin_amdgcn_s_waitcnt(0xc07f);
-      if constexpr (DB) {
+      if constexpr (MX) {
+        // Two fragment register sets by step parity.  Operand map of the instruction (found with exact integer data, tools/mx_probe*.py:
+        // CK's "32 consecutive k per lane" does not describe it): the 128-deep step is two 64-deep halves, lane (r = l & 15, g = l >> 4)
+        // holds k = 16 g .. 16 g + 15 of EACH half (bytes 0-15: first half, bytes 16-31: second half) -- chunks g and 4 + g of the 128-byte
+        // LDS row, the very chunks of the fp16 fragments -- while the scale it supplies belongs to block g = k in [32 g, 32 g + 32).
+        // The reads of step it + 1 are issued before the MFMAs of step it.
+        typedef int v8i __attribute__((ext_vector_type(8)));
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const unsigned xm0 = lds0 + (wm * TM + frow) * 128 + ((fq ^ swl) << 4), xm1 = lds0 + (wm * TM + frow) * 128 + (((4 + fq) ^ swl) << 4);
+        const unsigned wm0 = xm0 + XBYTES + (wn * TN - wm * TM) * 128, wm1 = xm1 + XBYTES + (wn * TN - wm * TM) * 128;
+        f16x8 wlo[2][NI], whi[2][NI], xlo[2][MI], xhi[2][MI];
+        int swv[2][NI], sxv[2][MI];
+        // scale bytes of this lane's rows: block index = 4 * (K-step) + fq; rows past the problem read row 0 (their results are dropped)
+        const unsigned char* swp[NI];
+        const unsigned char* sxp[MI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int n = n0 + wn * TN + i * 16 + frow;
+          swp[i] = p.mx_sw + (size_t)(n < p.N ? n : 0) * p.mx_ldsw + kbeg * 4 + fq;
+        }
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+          const int m = m0 + wm * TM + j * 16 + frow;
+          sxp[j] = p.mx_sx + (size_t)(m < p.M ? m : 0) * p.mx_ldsx + kbeg * 4 + fq;
+        }
+        auto rd = [&](auto SET, unsigned sb) {
+          constexpr int s_ = SET.value;
+          static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wlo[s_][I.value], wm0 + sb); lds_read128<I.value * 2048>(whi[s_][I.value], wm1 + sb); });
+          static_for<MI>([&](auto J) { lds_read128<J.value * 2048>(xlo[s_][J.value], xm0 + sb); lds_read128<J.value * 2048>(xhi[s_][J.value], xm1 + sb); });
+        };
+        auto scales = [&](auto SET, int step) {
+          constexpr int s_ = SET.value;
+#pragma unroll
+          for (int i = 0; i < NI; ++i) swv[s_][i] = swp[i][step * 4];
+#pragma unroll
+          for (int j = 0; j < MI; ++j) sxv[s_][j] = sxp[j][step * 4];
+        };
+        auto cat = [](const f16x8& lo, const f16x8& hi) -> v8i {
+          const v4i a = __builtin_bit_cast(v4i, lo), b = __builtin_bit_cast(v4i, hi);
+          return v8i{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        };
+        auto mm = [&](auto SET) {
+          constexpr int s_ = SET.value;
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const v8i w = cat(wlo[s_][i], whi[s_][i]);
+#pragma unroll
+            for (int j = 0; j < MI; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, cat(xlo[s_][j], xhi[s_][j]), acc[i][j], 0, 0, 0, swv[s_][i], 0, sxv[s_][j]);
+          }
+        };
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        __builtin_amdgcn_s_barrier();        // step 0 visible
+        rd(P0{}, 0u);
+        scales(P0{}, 0);
+        for (int it = 0; it < nk; it += 2) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          if (it + 1 < nk) {
+            __builtin_amdgcn_s_barrier();    // step it+1 visible; every MFMA wave holds step `it` in registers
+            rd(P1{}, ((it + 1) % STAGES) * STAGE);
+            scales(P1{}, it + 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mm(P0{});
+          __builtin_amdgcn_sched_barrier(0);
+          if (it + 1 >= nk) break;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          if (it + 2 < nk) {
+            __builtin_amdgcn_s_barrier();
+            rd(P0{}, ((it + 2) % STAGES) * STAGE);
+            scales(P0{}, it + 2);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mm(P1{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if constexpr (DB) {
         // Rotated loop: barrier `it+1` and the half-0 reads of step it+1 are issued BEFORE the half-1 MFMAs of step it,
         // the half-1 reads of step it+1 right after them, so every LDS round trip and the barrier hide under 32-deep
         // halves of MFMAs.  A wave reaches barrier it+1 only after lgkmcnt(0), i.e. with all its reads of step `it` in
@@ -759,8 +843,10 @@ static std::map<ShapeKey, std::pair<int, int>> g_tuned;
 // (the `ups` slot doubles as the epilogue class: 2 = GEGLU pair epilogue, whose tile menu is restricted)
 // (... and + 4 marks fp8 weights: a different kernel family with its own measurements)
 static ShapeKey key_of(const ConvGemm& p) {
-  return {p.M, p.N, p.K, p.Cin, p.R, p.stride, (p.act == 3 ? 2 : p.ups) + (p.wscale ? 4 : 0), p.Hi, p.Wi, p.B};
+  return {p.M, p.N, p.K, p.Cin, p.R, p.stride, (p.act == 3 ? 2 : p.ups) + (p.wscale ? 4 : 0) + (p.mx_sx ? 8 : 0), p.Hi, p.Wi, p.B};
 }
+// tiles instantiated for block-scaled fp8 operands (the MFMA-bound GEMMs: many rows)
+static bool tile_has_mx(int t) { return t == 0 || t == 1 || t == 6 || t == 7 || t == 21; }
 // tiles instantiated with fp8 weights (the weight-bound shapes: few rows, long K)
 static bool tile_has_w8(int t) { return t == 1 || t == 2 || t == 6 || t == 9 || t == 19 || t == 20; }
 
@@ -774,7 +860,7 @@ static Plan make_plan(const ConvGemm& p) {
     auto it = g_tuned.find(key_of(p));
     if (it != g_tuned.end() && !(pair && ((kTiles[it->second.first].bn / 2) % 32 != 0 || it->second.second != 1))) {
       const TileCfg& c = kTiles[it->second.first];
-      if ((c.kind != TK_HALO || halo_ok(p, c)) && (!p.wscale || tile_has_w8(it->second.first)))
+      if ((c.kind != TK_HALO || halo_ok(p, c)) && (!p.wscale || tile_has_w8(it->second.first)) && (!p.mx_sx || tile_has_mx(it->second.first)))
         return Plan{it->second.first, it->second.second, plan_nk(p, c), plan_tiles_m(p, c), cdiv(p.N, c.bn)};
     }
   }
@@ -784,6 +870,7 @@ static Plan make_plan(const ConvGemm& p) {
     auto usable = [&](int ti) {
       const TileCfg& cc = kTiles[ti];
       if (p.wscale && !tile_has_w8(ti)) return false;
+      if (p.mx_sx && !tile_has_mx(ti)) return false;
       if (cc.kind == TK_HALO) return halo_ok(p, cc);
       return (cc.kind == TK_DMA) == fast && !(pair && (cc.bn / 2) % 32 != 0);
     };
@@ -935,6 +1022,7 @@ static int prepare(const ConvGemm& p, Plan& pl, KP& kp) {
                "conv_gemm: fp8 weights need Cin %% 64 == 0 (Cin=%d), no folded upsample and 16-byte aligned rows (ldw=%d bytes)", p.Cin, p.ldw);
   pl = make_plan(p);
   SDEO_CHECK(!p.wscale || (tile_has_w8(pl.tile) && kTiles[pl.tile].kind == TK_DMA), "conv_gemm: no fp8-weight plan for this shape");
+  SDEO_CHECK(!p.mx_sx || (tile_has_mx(pl.tile) && kTiles[pl.tile].kind == TK_DMA), "conv_gemm: no block-scaled fp8 plan for this shape");
   SDEO_CHECK(p.act != 3 || (pl.splitk == 1 && (kTiles[pl.tile].bn / 2) % 32 == 0), "conv_gemm: no GEGLU-capable plan");
   kp = KP{};
   kp.x = p.x; kp.w = p.w; kp.y = p.y; kp.y32 = p.y32; kp.bias = p.bias; kp.bias2 = p.bias2; kp.res = p.res;
@@ -945,6 +1033,12 @@ static int prepare(const ConvGemm& p, Plan& pl, KP& kp) {
   kp.ldx = p.ldx; kp.ldw = p.ldw; kp.ldy = p.ldy; kp.ldres = p.ldres; kp.ld_bias2 = p.ld_bias2;
   kp.act = p.act; kp.bias_per_row = p.bias_per_row; kp.scale = p.scale;
   kp.wscale = p.wscale;
+  if (p.mx_sx) {       // (p arrives with K, Cin, ldx, ldw already halved: conv_gemm())
+    SDEO_CHECK(p.mx_sw && p.R == 1 && p.S == 1 && p.stride == 1 && !p.ups && !p.wscale && p.Cin % 64 == 0 && !p.bias_per_row,
+               "conv_gemm: block-scaled fp8 operands go with a plain GEMM whose K is a multiple of 128");
+    SDEO_CHECK(p.mx_ldsx >= p.K / 16 && p.mx_ldsw >= p.K / 16, "conv_gemm: scale rows too short (%d, %d < %d)", p.mx_ldsx, p.mx_ldsw, p.K / 16);
+    kp.mx_sx = p.mx_sx; kp.mx_sw = p.mx_sw; kp.mx_ldsx = p.mx_ldsx; kp.mx_ldsw = p.mx_ldsw;
+  }
   if (p.ln_stats) {
     SDEO_CHECK(p.ln_s && p.ln_strips >= 1 && p.ln_ld >= p.ln_strips && p.ln_c > 0, "conv_gemm: incomplete LayerNorm-fold arguments");
     SDEO_CHECK(!p.bias_per_row && !p.y32, "conv_gemm: the LayerNorm fold applies to row-major fp16 products only");
@@ -992,10 +1086,27 @@ static int prepare(const ConvGemm& p, Plan& pl, KP& kp) {
 }
 
 // launch the problem(s) in kp at plan `pl` (count is always 1)
+// block-scaled fp8 instantiations
+template <int BM, int BN, int ST>
+static int launch_dma_mx(const KP2& kp, int count, int tiles, hipStream_t stream) {
+  static DeviceOnce done;
+  constexpr int smem = ST * (BM + BN) * 128 + BM * 8;
+  return launch_k(&conv_gemm_dma_kernel<BM, BN, ST, false, true, false, 1, true>, smem, &done, kp, count, tiles, stream, 512);
+}
+
 static int dispatch(const Plan& pl, int ups, bool w8, const KP2& kp, int count, hipStream_t stream) {
   const int tiles = pl.tiles_m * pl.tiles_n;
   int rc = 0;
-  if (w8) {
+  if (kp.k[0].mx_sx) {
+    switch (pl.tile) {
+      case 0: rc = launch_dma_mx<128, 128, 3>(kp, count, tiles, stream); break;
+      case 1: rc = launch_dma_mx<128, 64, 3>(kp, count, tiles, stream); break;
+      case 6: rc = launch_dma_mx<64, 160, 3>(kp, count, tiles, stream); break;
+      case 7: rc = launch_dma_mx<128, 160, 3>(kp, count, tiles, stream); break;
+      case 21: rc = launch_dma_mx<128, 128, 4>(kp, count, tiles, stream); break;
+      default: return fail("conv_gemm: tile %d has no block-scaled fp8 instantiation", pl.tile);
+    }
+  } else if (w8) {
     switch (pl.tile) {
       case 1: rc = launch_dma_w8<128, 64, 3>(kp, count, tiles, stream); break;
       case 2: rc = launch_dma_w8<64, 64, 4>(kp, count, tiles, stream); break;
@@ -1054,7 +1165,12 @@ static int dispatch(const Plan& pl, int ups, bool w8, const KP2& kp, int count, 
   return 0;
 }
 
-int conv_gemm(const ConvGemm& p, hipStream_t stream) {
+int conv_gemm(const ConvGemm& p0, hipStream_t stream) {
+  ConvGemm p = p0;
+  if (p.mx_sx) {       // fp8 codes addressed as an fp16 problem of half the length (KP::mx_sx)
+    SDEO_CHECK(p.K % 128 == 0 && p.ldx % 16 == 0 && p.ldw % 16 == 0 && p.K == p.Cin, "conv_gemm: block-scaled fp8 GEMM needs K %% 128 == 0 (K=%d, ldx=%d, ldw=%d)", p.K, p.ldx, p.ldw);
+    p.K /= 2; p.Cin /= 2; p.ldx /= 2; p.ldw /= 2;
+  }
   Plan pl;
   KP2 kk{};
   if (int rc = prepare(p, pl, kk.k[0])) return rc;

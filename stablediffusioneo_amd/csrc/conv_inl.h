@@ -50,6 +50,12 @@ struct KP {
   //      the consumer sums the gn_slots entries of a group in a fixed order (deterministic, no atomics).
   float* gn_out;           // [B][gn_slots][gn_groups][2]; null = off
   int gn_cpg, gn_slots, gn_groups;
+  // ---- block-scaled fp8 operands (conv_gemm_dma_kernel<..., MX>, GEMM only): x and w hold OCP e4m3fn codes (one byte per element,
+  //      addressed through this block as fp16 arrays of half the length: K, Cin, ldx, ldw count PAIRS of codes), mx_sx / mx_sw one
+  //      e8m0 scale byte per 32 codes of a row.  The MFMA is v_mfma_scale_f32_16x16x128_f8f6f4: 128 codes per K-step.
+  const unsigned char* mx_sx;   // [M][mx_ldsx]; null = off
+  const unsigned char* mx_sw;   // [N][mx_ldsw]
+  int mx_ldsx, mx_ldsw;
 };
 
 // what a kernel receives (blockIdx.y indexes the problem; always one)

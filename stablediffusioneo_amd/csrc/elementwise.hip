@@ -482,6 +482,48 @@ int quantize_fp8_rows(uint8_t* q, float* scale, f16* w, int rows, int cols, int 
   return 0;
 }
 
+// block-scaled fp8 pack (kernels.h quantize_mx): thread = 8 elements, four neighbouring lanes = one 32-element block
+__global__ __launch_bounds__(256) void quantize_mx_kernel(uint8_t* __restrict__ q, uint8_t* __restrict__ scales, const f16* __restrict__ x,
+                                                          int rows, int cols, int ldx, int ldq, int lds) {
+  const int vpr = cols / 8;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = id < (int64_t)rows * vpr;
+  const int r = live ? (int)(id / vpr) : 0, v = live ? (int)(id - (int64_t)r * vpr) : 0;
+  f16x8 val = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  if (live) val = *reinterpret_cast<const f16x8*>(x + (size_t)r * ldx + v * 8);
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf((float)val[j]));
+  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));       // cols % 32 == 0: the four lanes of a block are live or dead together
+  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+  int e = 0;
+  if (amax > 0.f) {
+    int ex;
+    const float m = frexpf(amax, &ex);                // amax = m * 2^ex, m in [0.5, 1);  448 = 0.875 * 2^9
+    e = m <= 0.875f ? ex - 9 : ex - 8;
+  }
+  const float inv = ldexpf(1.0f, -e);
+  unsigned lo = 0, hi = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const unsigned c = e4m3fn_encode((float)val[j] * inv);
+    if (j < 4) lo |= c << (8 * j); else hi |= c << (8 * (j - 4));
+  }
+  if (live) {
+    *reinterpret_cast<uint2*>(q + (size_t)r * ldq + v * 8) = make_uint2(lo, hi);
+    if ((v & 3) == 0) scales[(size_t)r * lds + (v >> 2)] = (uint8_t)(e + 127);
+  }
+}
+
+int quantize_mx(uint8_t* q, uint8_t* scales, const f16* x, int rows, int cols, int ldx, int ldq, int lds, hipStream_t stream) {
+  SDEO_CHECK(q && scales && x && rows > 0 && cols > 0 && cols % 32 == 0 && ldx % 8 == 0 && ldq % 8 == 0 && lds >= cols / 32,
+             "quantize_mx: bad operand (cols %d, ldx %d, ldq %d, lds %d)", cols, ldx, ldq, lds);
+  const int64_t n = (int64_t)rows * (cols / 8);
+  hipLaunchKernelGGL(quantize_mx_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, stream, q, scales, x, rows, cols, ldx, ldq, lds);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
 // s[r] = sum_k w[r][k]  (row sums of a LayerNorm-folded matrix after it was re-quantised: KP::ln_s must match the streamed weights)
 __global__ __launch_bounds__(256) void row_sums_kernel(float* __restrict__ s_out, const f16* __restrict__ w, int rows, int C) {
   const int lane = threadIdx.x & 63;

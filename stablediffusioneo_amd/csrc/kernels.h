@@ -50,6 +50,11 @@ struct ConvGemm {
   // group over the rows of one M tile of image b; gn_slots must equal conv_gemm_gn_slots(p, gn_cpg) (> 0)
   float* gn_out = nullptr;
   int gn_cpg = 0, gn_slots = 0, gn_groups = 0;
+  // block-scaled fp8 GEMM (both operands OCP e4m3fn codes + one e8m0 scale byte per 32 codes of a row, quantize_mx): x and w point at
+  // BYTES, K / ldx / ldw count codes, K % 128 == 0, R = S = 1.  Runs on v_mfma_scale_f32_16x16x128_f8f6f4.
+  const uint8_t* mx_sx = nullptr;  // [M][mx_ldsx]
+  const uint8_t* mx_sw = nullptr;  // [N][mx_ldsw]
+  int mx_ldsx = 0, mx_ldsw = 0;
 };
 int conv_gemm(const ConvGemm& p, hipStream_t stream);
 // M tiles per image of the plan chosen for p when its epilogue can emit GroupNorm partials for groups of cpg channels, else 0
@@ -154,6 +159,9 @@ int row_stats(float* stats, int ld, const f16* x, int ldx, int rows, int C, hipS
 // fp8 weight pack: q[r][0:cols] = e4m3fn codes of w[r] / scale[r] (scale = power of two, absmax / scale <= 448) and w <- code * scale
 int quantize_fp8_rows(uint8_t* q, float* scale, f16* w, int rows, int cols, int ldw, int ldq, hipStream_t stream);
 int row_sums_f16(float* s_out, const f16* w, int rows, int C, hipStream_t stream);
+// block-scaled fp8 pack of a [rows][cols] fp16 matrix (cols % 32 == 0): per 32 consecutive elements of a row one e8m0 scale byte
+// (2^(s - 127): the smallest power of two with amax / scale <= 448; 127 for an all-zero block) and 32 e4m3fn codes of x / scale
+int quantize_mx(uint8_t* q, uint8_t* scales, const f16* x, int rows, int cols, int ldx, int ldq, int lds, hipStream_t stream);
 // CLIP text embeddings: out[(b*T + t)][0:W] = tok_emb[ids[b*T + t]][0:W] + pos_emb[t][0:W]   (ids are clamped to [0, vocab))
 int embed_tokens(f16* out, const int32_t* ids, const f16* tok_emb, const f16* pos_emb, int B, int T, int W, int vocab,
                  hipStream_t stream);

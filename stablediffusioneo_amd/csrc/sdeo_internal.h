@@ -43,6 +43,11 @@ int sdeo_debug_conv2d_gn_f16(void* ynorm, void* y, const void* x, const void* w_
 /* fp8 weight pack at op level (tests): quantise [rows][cols] fp16 in place to its dequantised values, codes -> q, scales -> scale;
  * sdeo_debug_next_weights_fp8 makes the NEXT sdeo_gemm_f16 / sdeo_conv2d_nhwc_f16 call of this thread stream these codes
  * (K-contiguous bytes, same [N][K] / KRSC layout) instead of its fp16 weight argument */
+/* block-scaled fp8 (e4m3fn codes + one e8m0 scale per 32 elements of a row) at op level: the pack of an fp16 [rows][cols] matrix
+ * (q_out [rows][cols] bytes, scales_out [rows][cols / 32] bytes) and y = x w^T on two packed operands with v_mfma_scale_f32_16x16x128_f8f6f4 */
+int sdeo_debug_quantize_mx(void* q_out, void* scales_out, const void* x, int rows, int cols, void* stream);
+int sdeo_debug_gemm_mx_f16(void* y, int ldy, const void* xq, const void* xs, const void* wq, const void* ws, const float* bias, const void* res,
+                           int ldres, int m, int n, int k, int act, void* workspace, size_t workspace_bytes, void* stream);
 int sdeo_debug_quantize_fp8_rows(void* w_f16_inout, void* q_out, float* scale_out, int rows, int cols, void* stream);
 void sdeo_debug_next_weights_fp8(const void* q, const float* scale);
 

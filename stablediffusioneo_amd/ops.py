@@ -60,6 +60,33 @@ def quantize_fp8_rows(w):
     return q.reshape(w.shape), sc, wd.reshape(w.shape)
 
 
+def quantize_mx(x):
+    """block-scaled fp8 pack of an fp16 [rows][cols] matrix (cols % 32 == 0): (codes uint8 [rows][cols], e8m0 scales uint8 [rows][cols/32])"""
+    lib = _lib.load()
+    _need_cuda(x)
+    rows, cols = x.shape
+    assert x.dtype == torch.float16 and x.is_contiguous() and cols % 32 == 0
+    q = torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
+    sc = torch.empty((rows, cols // 32), dtype=torch.uint8, device=x.device)
+    check(lib.sdeo_debug_quantize_mx(ptr(q), ptr(sc), ptr(x), _i(rows), _i(cols), cur_stream()), "quantize_mx")
+    return q, sc
+
+
+def gemm_mx(xq, xs, wq, ws, bias=None, res=None, act=0):
+    """y[m][n] = sum_k dequant(x)[m][k] dequant(w)[n][k] (+bias)(+res) on block-scaled fp8 operands (quantize_mx), K % 128 == 0; fp16 out"""
+    lib = _lib.load()
+    _need_cuda(xq, wq)
+    m, k = xq.shape
+    n = wq.shape[0]
+    assert k % 128 == 0 and wq.shape[1] == k and xs.shape == (m, k // 32) and ws.shape == (n, k // 32)
+    y = torch.empty((m, n // 2 if act == 3 else n), dtype=torch.float16, device=xq.device)
+    wsb = _ws(64 << 20, xq.device)
+    check(lib.sdeo_debug_gemm_mx_f16(ptr(y), _i(y.shape[1]), ptr(xq), ptr(xs), ptr(wq), ptr(ws), ptr(bias), ptr(res),
+                                     _i(res.stride(0) if res is not None else 0), _i(m), _i(n), _i(k), _i(act), ptr(wsb),
+                                     C.c_size_t(wsb.numel()), cur_stream()), "gemm_mx")
+    return y
+
+
 def _arm_fp8(lib, w8):
     if w8 is not None:
         q, sc = w8
