@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--config", default="sd15", choices=["sd15", "tiny"])
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE configs[4]: UNet / ControlNet matrices packed to fp8 e4m3fn (per-output-channel scales), fp16 activations")
+    ap.add_argument("--mx", action="store_true",
+                    help="with --fp8: the GEMMs of >= --mx-min-rows rows run block-scaled fp8 x fp8 on v_mfma_scale_f32_16x16x128_f8f6f4 "
+                         "(activations packed to e4m3fn + e8m0 block scales in front of each such GEMM)")
+    ap.add_argument("--mx-min-rows", type=int, default=2048)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (the CFG pair makes N = 2 x batch)")
     ap.add_argument("--fast-weights", action="store_true",
                     help="draw the synthetic weights with the device generator (seconds faster to start; NOT the parity-tested weights, "
@@ -167,7 +171,7 @@ def main():
     from tests.common import X_T_SEED, make_hint, randn
 
     ucfg, vcfg = (S.UNET_SD15, S.VAE_SD15) if a.config == "sd15" else (S.UNET_TINY, S.VAE_TINY)
-    rt = SdeoRuntime(ucfg, vcfg, device=dev, weight_bits=8 if a.fp8 else 16)
+    rt = SdeoRuntime(ucfg, vcfg, device=dev, weight_bits=8 if a.fp8 else 16, act_bits=8 if (a.fp8 and a.mx) else 16, mx_min_rows=a.mx_min_rows)
     if a.fast_weights:
         rt.load_synthetic_device(0)
     else:
@@ -255,6 +259,27 @@ def main():
                         "mean_abs_err_over_ref_max": round(float(err.mean() / zref.abs().max()), 6)}
         assert golden_check["max_abs_err_over_ref_max"] < 5e-2, f"benchmarked output is off the reference golden: {golden_check}"
 
+    fp8_check = None
+    fpath = os.path.join(ROOT, "tests", "golden", "sd15_fp8.npz")
+    if rank == 0 and a.fp8 and not a.fast_weights and a.config == "sd15" and a.res == 512 and os.path.exists(fpath):
+        # distance of ONE pass (N = 2, t = 951) to the reference modules run in fp32 on the same fp8-dequantised weights
+        # (tests/golden/make_golden_full.py --only pass64_fp8): what is left is the activation precision (fp16, or block-scaled fp8 with --mx)
+        import numpy as np
+        from stablediffusioneo_amd import _lib as L
+        import ctypes as C
+        x1 = randn((1, 4, h, w), X_T_SEED)
+        xx = torch.cat([x1, x1]).to(dev)
+        hint1 = make_hint(1, a.res, a.res)
+        cc = torch.cat([randn((1, 77, 768), 1), randn((1, 77, 768), 2)]).to(dev)
+        rt.configure(2, h, w)
+        eps = rt.apply_model(xx, torch.cat([hint1, hint1]).to(dev), torch.tensor([951, 951], dtype=torch.long, device=dev), cc, scales=[1.0] * 13)
+        ref = torch.tensor(np.load(fpath)["pass64_fp8.eps"])
+        err = (eps.float().cpu() - ref).abs()
+        L.load().sdeo_debug_mx_launches.argtypes = [C.c_void_p]
+        fp8_check = {"what": "eps of one N=2 pass vs the reference modules (fp32) on the same fp8-dequantised weights (pass64_fp8.eps)",
+                     "max_abs_err_over_ref_max": round(float(err.max() / ref.abs().max()), 5),
+                     "mean_abs_err_over_ref_max": round(float(err.mean() / ref.abs().max()), 6),
+                     "gemm_launches_on_fp8_mfma_per_pass": int(L.load().sdeo_debug_mx_launches(rt.handle))}
     roof = None
     if not a.no_roofline and rank == 0:
         import stablediffusioneo_amd.cldm.ddim_hacked as dh
@@ -328,12 +353,13 @@ def main():
             "metric": "512x512 canny2image images/sec (20 DDIM steps); ms per UNet step reported alongside",
             "value": round(images / elapsed, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16 (fp8 e4m3fn weights)" if a.fp8 else "f16", "data": "synthetic",
+            "dtype": ("f16 + block-scaled fp8 x fp8 GEMMs (fp8 e4m3fn weights)" if a.mx else "f16 (fp8 e4m3fn weights)") if a.fp8 else "f16", "data": "synthetic",
             "ms_per_unet_step": round(loop_ms / a.ddim_steps, 3),
             "mfma_frac_whole_image": round(flop_img / per_image_s / 1e12 / PEAK_TFLOPS_F16, 4) if flop_img else None,
             "config": {"workload": f"SD1.5 + ControlNet-canny {a.res}x{a.res}, batch={B} per GPU (CFG pair fused, N={2 * B}), "
                                    f"{a.ddim_steps} DDIM steps + VAE decode, fp16 storage / fp32 accumulate"
-                                   + (", UNet / ControlNet weights fp8 e4m3fn with per-output-channel scales (BASELINE configs[4] shape)" if a.fp8
+                                   + (", UNet / ControlNet weights fp8 e4m3fn with per-output-channel scales (BASELINE configs[4] precision"
+                                      + (f"; GEMMs of >= {a.mx_min_rows} rows block-scaled fp8 x fp8 on the fp8 MFMA" if a.mx else "; fp16 MFMA") + ")" if a.fp8
                                       else " (BASELINE configs[1])"),
                        "model_config": a.config, "images_per_gpu_per_step": B, "ddim_steps": a.ddim_steps,
                        "guidance_scale": a.scale, "parallelism": f"dp{world} (image index -> rank, RCCL all_gather of final latents)",
@@ -344,6 +370,8 @@ def main():
             out["per_rank_images_per_s"] = per_rank
         if golden_check:
             out["output_check"] = golden_check
+        if fp8_check:
+            out["fp8_check"] = fp8_check
         if roof:
             out["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline and a.config == "sd15":

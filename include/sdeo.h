@@ -170,6 +170,13 @@ int sdeo_finalize_weights(sdeo_handle h);
  * sdeo_finalize_weights.  The weight-bound shapes (<= 512 rows) stream the one-byte codes; every other kernel reads an fp16 copy
  * holding the same dequantised values. */
 int sdeo_set_weight_precision(sdeo_handle h, int bits);
+/* Activation precision of the large GEMMs (Linear / conv1x1 with >= min_rows rows and K a multiple of 128), meaningful with 8-bit
+ * weights only: 16 = fp16 activations (default); 8 = block-scaled fp8 on both sides -- the activations are packed to e4m3fn codes with
+ * one e8m0 scale per 32 channels right in front of the GEMM, the matrix is packed the same way by sdeo_finalize_weights, and the
+ * product runs on the block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, twice the fp16 rate).  Everything else (3x3 convs,
+ * attention, small GEMMs, norms, VAE) stays as with sdeo_set_weight_precision(h, 8).  Call before sdeo_finalize_weights.
+ * min_rows <= 0 selects the default threshold (2048). */
+int sdeo_set_activation_precision(sdeo_handle h, int bits, int min_rows);
 /* Number of expected tensors and the i-th expected name/shape (ndim<=4), for loaders and tests. */
 int sdeo_num_weights(sdeo_handle h);
 int sdeo_weight_info(sdeo_handle h, int i, const char** name, int64_t dims[4], int* ndim);

@@ -361,8 +361,8 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
         typedef int v4i __attribute__((ext_vector_type(4)));
         const unsigned xm0 = lds0 + (wm * TM + frow) * 128 + ((fq ^ swl) << 4), xm1 = lds0 + (wm * TM + frow) * 128 + (((4 + fq) ^ swl) << 4);
         const unsigned wm0 = xm0 + XBYTES + (wn * TN - wm * TM) * 128, wm1 = xm1 + XBYTES + (wn * TN - wm * TM) * 128;
-        f16x8 wlo[2][NI], whi[2][NI], xlo[2][MI], xhi[2][MI];
-        int swv[2][NI], sxv[2][MI];
+        f16x8 wlo[NI], whi[NI], xlo[MI], xhi[MI];
+        int swv[NI], sxv[MI];
         // scale bytes of this lane's rows: block index = 4 * (K-step) + fq; rows past the problem read row 0 (their results are dropped)
         const unsigned char* swp[NI];
         const unsigned char* sxp[MI];
@@ -376,59 +376,39 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
           const int m = m0 + wm * TM + j * 16 + frow;
           sxp[j] = p.mx_sx + (size_t)(m < p.M ? m : 0) * p.mx_ldsx + kbeg * 4 + fq;
         }
-        auto rd = [&](auto SET, unsigned sb) {
-          constexpr int s_ = SET.value;
-          static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wlo[s_][I.value], wm0 + sb); lds_read128<I.value * 2048>(whi[s_][I.value], wm1 + sb); });
-          static_for<MI>([&](auto J) { lds_read128<J.value * 2048>(xlo[s_][J.value], xm0 + sb); lds_read128<J.value * 2048>(xhi[s_][J.value], xm1 + sb); });
-        };
-        auto scales = [&](auto SET, int step) {
-          constexpr int s_ = SET.value;
-#pragma unroll
-          for (int i = 0; i < NI; ++i) swv[s_][i] = swp[i][step * 4];
-#pragma unroll
-          for (int j = 0; j < MI; ++j) sxv[s_][j] = sxp[j][step * 4];
+        auto rd = [&](unsigned sb) {
+          static_for<NI>([&](auto I) { lds_read128<I.value * 2048>(wlo[I.value], wm0 + sb); lds_read128<I.value * 2048>(whi[I.value], wm1 + sb); });
+          static_for<MI>([&](auto J) { lds_read128<J.value * 2048>(xlo[J.value], xm0 + sb); lds_read128<J.value * 2048>(xhi[J.value], xm1 + sb); });
         };
         auto cat = [](const f16x8& lo, const f16x8& hi) -> v8i {
           const v4i a = __builtin_bit_cast(v4i, lo), b = __builtin_bit_cast(v4i, hi);
           return v8i{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
         };
-        auto mm = [&](auto SET) {
-          constexpr int s_ = SET.value;
+        // ONE fragment set (two spilled at the 256-register cap of an 8-wave workgroup): an MFMA reads its operands at issue, so the
+        // reads of step it + 1 are issued right behind the last MFMA of step it and land while the matrix pipe works through them
+        __builtin_amdgcn_s_barrier();        // step 0 visible
+        rd(0u);
+        for (int it = 0; it < nk; ++it) {
+          int swn[NI], sxn[MI];
+#pragma unroll
+          for (int i = 0; i < NI; ++i) swv[i] = swp[i][it * 4];
+#pragma unroll
+          for (int j = 0; j < MI; ++j) sxv[j] = sxp[j][it * 4];
+          (void)swn; (void)sxn;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int i = 0; i < NI; ++i) {
-            const v8i w = cat(wlo[s_][i], whi[s_][i]);
+            const v8i w = cat(wlo[i], whi[i]);
 #pragma unroll
             for (int j = 0; j < MI; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, cat(xlo[s_][j], xhi[s_][j]), acc[i][j], 0, 0, 0, swv[s_][i], 0, sxv[s_][j]);
+              acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w, cat(xlo[j], xhi[j]), acc[i][j], 0, 0, 0, swv[i], 0, sxv[j]);
           }
-        };
-        using P0 = std::integral_constant<int, 0>;
-        using P1 = std::integral_constant<int, 1>;
-        __builtin_amdgcn_s_barrier();        // step 0 visible
-        rd(P0{}, 0u);
-        scales(P0{}, 0);
-        for (int it = 0; it < nk; it += 2) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           if (it + 1 < nk) {
-            __builtin_amdgcn_s_barrier();    // step it+1 visible; every MFMA wave holds step `it` in registers
-            rd(P1{}, ((it + 1) % STAGES) * STAGE);
-            scales(P1{}, it + 1);
+            __builtin_amdgcn_s_barrier();    // step it+1 visible; every MFMA wave has issued (= read the operands of) step `it`
+            rd(((it + 1) % STAGES) * STAGE);
           }
-          __builtin_amdgcn_sched_barrier(0);
-          mm(P0{});
-          __builtin_amdgcn_sched_barrier(0);
-          if (it + 1 >= nk) break;
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-          if (it + 2 < nk) {
-            __builtin_amdgcn_s_barrier();
-            rd(P0{}, ((it + 2) % STAGES) * STAGE);
-            scales(P0{}, it + 2);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          mm(P1{});
-          __builtin_amdgcn_sched_barrier(0);
         }
       } else if constexpr (DB) {
         // Rotated loop: barrier `it+1` and the half-0 reads of step it+1 are issued BEFORE the half-1 MFMAs of step it,
@@ -846,7 +826,7 @@ static ShapeKey key_of(const ConvGemm& p) {
   return {p.M, p.N, p.K, p.Cin, p.R, p.stride, (p.act == 3 ? 2 : p.ups) + (p.wscale ? 4 : 0) + (p.mx_sx ? 8 : 0), p.Hi, p.Wi, p.B};
 }
 // tiles instantiated for block-scaled fp8 operands (the MFMA-bound GEMMs: many rows)
-static bool tile_has_mx(int t) { return t == 0 || t == 1 || t == 6 || t == 7 || t == 21; }
+static bool tile_has_mx(int t) { return t == 0 || t == 1 || t == 6 || t == 21; }      // (<128,160,3> spills at the 256-register cap)
 // tiles instantiated with fp8 weights (the weight-bound shapes: few rows, long K)
 static bool tile_has_w8(int t) { return t == 1 || t == 2 || t == 6 || t == 9 || t == 19 || t == 20; }
 
@@ -913,20 +893,30 @@ static Plan make_plan(const ConvGemm& p) {
   return best;
 }
 
+// block-scaled fp8 operands are addressed as an fp16 problem of half the length (KP::mx_sx): every plan query sees that view
+static ConvGemm mx_view(const ConvGemm& p0) {
+  ConvGemm p = p0;
+  if (p.mx_sx) { p.K /= 2; p.Cin /= 2; p.ldx /= 2; p.ldw /= 2; }
+  return p;
+}
+
 // columns per epilogue strip of a plan: the wave tile width of the implicit-GEMM kernels, the whole tile of the halo kernel
 static int plan_tn(const Plan& pl) { return kTiles[pl.tile].kind == TK_HALO ? kTiles[pl.tile].bn : kTiles[pl.tile].bn / 2; }
 
-int conv_gemm_stats_strips(const ConvGemm& p) {
+int conv_gemm_stats_strips(const ConvGemm& p0) {
+  const ConvGemm p = mx_view(p0);
   const Plan pl = make_plan(p);
   return pl.splitk == 1 ? cdiv(p.N, plan_tn(pl)) : 0;
 }
 
-bool conv_gemm_plan_is_halo(const ConvGemm& p) { return kTiles[make_plan(p).tile].kind == TK_HALO; }
+bool conv_gemm_plan_is_halo(const ConvGemm& p) { return kTiles[make_plan(mx_view(p)).tile].kind == TK_HALO; }
 
 // GroupNorm partials from the epilogue (KP::gn_out): entries per image the plan of p writes for groups of `cpg` channels, or 0 when it
 // cannot (split-K, a strip that cuts a group, a tile that straddles two images, the register-staged fallback kernel, an epilogue
 // that is not the LDS-transposed one)
-int conv_gemm_gn_slots(const ConvGemm& p, int cpg) {
+static int gn_slots_of(const ConvGemm& p, int cpg);
+int conv_gemm_gn_slots(const ConvGemm& p0, int cpg) { return gn_slots_of(mx_view(p0), cpg); }
+static int gn_slots_of(const ConvGemm& p, int cpg) {       // p: the view the kernels see (mx_view)
   if (cpg <= 0 || p.N % cpg || p.act == 3 || p.y32 || !p.y || p.bias_per_row || p.stats_out) return 0;
   const Plan pl = make_plan(p);
   const TileCfg& c = kTiles[pl.tile];
@@ -937,13 +927,14 @@ int conv_gemm_gn_slots(const ConvGemm& p, int cpg) {
   return hw % c.bm == 0 ? hw / c.bm : 0;
 }
 
-size_t conv_gemm_workspace_bytes(const ConvGemm& p) {
+size_t conv_gemm_workspace_bytes(const ConvGemm& p0) {
+  const ConvGemm p = mx_view(p0);
   const Plan pl = make_plan(p);
   return pl.splitk > 1 ? (size_t)pl.splitk * p.M * p.N * sizeof(float) : 0;
 }
 
-const char* conv_gemm_kernel_name(const ConvGemm& p) { return kTiles[make_plan(p).tile].name; }
-int conv_gemm_plan_splitk(const ConvGemm& p) { return make_plan(p).splitk; }
+const char* conv_gemm_kernel_name(const ConvGemm& p) { return kTiles[make_plan(mx_view(p)).tile].name; }
+int conv_gemm_plan_splitk(const ConvGemm& p) { return make_plan(mx_view(p)).splitk; }
 
 template <typename K>
 static int launch_k(K kernel, int smem, DeviceOnce* attr_done, const KP2& kp, int count, int tiles, hipStream_t stream, int threads = 256) {
@@ -1052,7 +1043,7 @@ static int prepare(const ConvGemm& p, Plan& pl, KP& kp) {
     kp.stats_out = p.stats_out; kp.stats_ld = p.stats_ld;
   }
   if (p.gn_out) {
-    const int slots = conv_gemm_gn_slots(p, p.gn_cpg);
+    const int slots = gn_slots_of(p, p.gn_cpg);
     SDEO_CHECK(slots > 0 && slots == p.gn_slots && p.gn_groups * p.gn_cpg == p.N,
                "conv_gemm: GroupNorm partials need an unsplit fp16 plan whose strips cover whole groups (slots %d, expected %d)", slots, p.gn_slots);
     kp.gn_out = p.gn_out; kp.gn_cpg = p.gn_cpg; kp.gn_slots = p.gn_slots; kp.gn_groups = p.gn_groups;
@@ -1102,7 +1093,6 @@ static int dispatch(const Plan& pl, int ups, bool w8, const KP2& kp, int count, 
       case 0: rc = launch_dma_mx<128, 128, 3>(kp, count, tiles, stream); break;
       case 1: rc = launch_dma_mx<128, 64, 3>(kp, count, tiles, stream); break;
       case 6: rc = launch_dma_mx<64, 160, 3>(kp, count, tiles, stream); break;
-      case 7: rc = launch_dma_mx<128, 160, 3>(kp, count, tiles, stream); break;
       case 21: rc = launch_dma_mx<128, 128, 4>(kp, count, tiles, stream); break;
       default: return fail("conv_gemm: tile %d has no block-scaled fp8 instantiation", pl.tile);
     }
@@ -1166,11 +1156,9 @@ static int dispatch(const Plan& pl, int ups, bool w8, const KP2& kp, int count, 
 }
 
 int conv_gemm(const ConvGemm& p0, hipStream_t stream) {
-  ConvGemm p = p0;
-  if (p.mx_sx) {       // fp8 codes addressed as an fp16 problem of half the length (KP::mx_sx)
-    SDEO_CHECK(p.K % 128 == 0 && p.ldx % 16 == 0 && p.ldw % 16 == 0 && p.K == p.Cin, "conv_gemm: block-scaled fp8 GEMM needs K %% 128 == 0 (K=%d, ldx=%d, ldw=%d)", p.K, p.ldx, p.ldw);
-    p.K /= 2; p.Cin /= 2; p.ldx /= 2; p.ldw /= 2;
-  }
+  if (p0.mx_sx)        // fp8 codes addressed as an fp16 problem of half the length (KP::mx_sx)
+    SDEO_CHECK(p0.K % 128 == 0 && p0.ldx % 16 == 0 && p0.ldw % 16 == 0 && p0.K == p0.Cin, "conv_gemm: block-scaled fp8 GEMM needs K %% 128 == 0 (K=%d, ldx=%d, ldw=%d)", p0.K, p0.ldx, p0.ldw);
+  const ConvGemm p = mx_view(p0);
   Plan pl;
   KP2 kk{};
   if (int rc = prepare(p, pl, kk.k[0])) return rc;
@@ -1221,6 +1209,7 @@ size_t conv_gemm_autotune_workspace_bytes(const ConvGemm& p) {
 }
 
 int conv_gemm_autotune(const ConvGemm& p, hipStream_t stream) {
+  if (p.mx_sx) return 0;                                   // block-scaled fp8 GEMMs run on the heuristic plan among their few tiles
   if (!is_fast(p) || g_force_tile >= 0 || g_force_splitk > 0) return 0;
   const ShapeKey key = key_of(p);
   if (g_tuned.count(key)) return 0;

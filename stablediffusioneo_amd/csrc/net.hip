@@ -222,6 +222,12 @@ struct sdeo_handle_s {
   std::vector<QRegion> qregions;
   std::unordered_map<size_t, int> qindex;              // fp16 slab offset -> qregions index
   int weight_bits = 16;                                // 8: fp8 e4m3fn weights for the UNet / ControlNet matrices
+  int act_bits = 16, mx_min_rows = 2048;               // 8: block-scaled fp8 activations x weights for GEMMs of >= mx_min_rows rows
+  char* mxslab = nullptr;                              // block-scaled packs of the matrices (codes + e8m0 scales)
+  size_t mx_bytes = 0;
+  struct MxRegion { size_t q_off, s_off; int rows, cols; };
+  std::unordered_map<size_t, MxRegion> mxindex;        // fp16 slab offset of a matrix -> its block-scaled pack
+  int mx_launches = 0;                                 // GEMMs of the current programs that run on the block-scaled fp8 MFMA
   char* q8slab = nullptr;                              // fp8 codes + scales (allocated at the first fp8 finalize)
   size_t q8_bytes = 0;
   char* wslab = nullptr;
@@ -553,7 +559,27 @@ struct Builder {
 
 
   void launch_conv(ConvGemm p, const float* scale_host, RowStats* stats = nullptr, T* gn_y = nullptr) {
-    if (e->weight_bits == 8 && p.M <= 512 && p.Cin % 64 == 0 && !p.ups && !p.bias_per_row && !conv_gemm_plan_is_halo(p)) {
+    if (e->act_bits == 8 && e->mxslab && p.M >= e->mx_min_rows && p.R == 1 && p.S == 1 && p.stride == 1 && !p.ups && p.K % 128 == 0 &&
+        p.K == p.Cin && p.ldx % 16 == 0 && !p.bias_per_row && p.y && !p.y32) {
+      // block-scaled fp8 on both sides: pack the activations (one launch), run the GEMM on the fp8 MFMA
+      auto it = e->mxindex.find((size_t)(reinterpret_cast<const char*>(p.w) - e->wslab));
+      if (it != e->mxindex.end() && it->second.cols == p.ldw && p.N <= it->second.rows) {
+        T xq = alloc2d(p.M, p.K / 2), xs = alloc2d(p.M, (p.K / 32 + 15) / 16 * 8);      // bytes: M x K codes, M x roundup(K/32, 16) scales
+        uint8_t* q = reinterpret_cast<uint8_t*>(xq.p);
+        uint8_t* sc = reinterpret_cast<uint8_t*>(xs.p);
+        const int lds = (p.K / 32 + 15) / 16 * 16;
+        const f16* xp = p.x; const int M_ = p.M, K_ = p.K, ldx_ = p.ldx;
+        push([=](hipStream_t s) { return quantize_mx(q, sc, xp, M_, K_, ldx_, K_, lds, s); }, "quantize_mx", 0, 3.0 * M_ * K_,
+             "rows" + std::to_string(M_) + " C" + std::to_string(K_));
+        p.x = reinterpret_cast<const f16*>(q); p.ldx = p.K;
+        p.w = reinterpret_cast<const f16*>(e->mxslab + it->second.q_off); p.ldw = it->second.cols;
+        p.mx_sx = sc; p.mx_ldsx = lds;
+        p.mx_sw = reinterpret_cast<const uint8_t*>(e->mxslab + it->second.s_off); p.mx_ldsw = it->second.cols / 32;
+        ++e->mx_launches;
+        mx_tmp.push_back(xq); mx_tmp.push_back(xs);
+      }
+    }
+    if (!p.mx_sx && e->weight_bits == 8 && p.M <= 512 && p.Cin % 64 == 0 && !p.ups && !p.bias_per_row && !conv_gemm_plan_is_halo(p)) {
       // weight-bound shapes stream the fp8 copy of their matrix (same numbers: the fp16 copy holds the dequantised values); where
       // the measured fp16 plan is a halo-reuse 3x3 kernel (activation-bound: M = 512 at long K) that kernel keeps the job
       auto it = e->qindex.find((size_t)(reinterpret_cast<const char*>(p.w) - e->wslab));
@@ -602,6 +628,8 @@ struct Builder {
        2.0 * ((double)p.M * p.Cin * (p.R * p.S > 1 ? 1 : 1) + (double)p.N * p.K + (double)p.M * p.N),
        "M" + std::to_string(p.M) + " N" + std::to_string(p.N) + " K" + std::to_string(p.K) + " R" + std::to_string(p.R) + " s" +
            std::to_string(p.stride) + " u" + std::to_string(p.ups));
+    for (auto& t : mx_tmp) release(t);       // the packed activations live for this one launch
+    mx_tmp.clear();
     if (stats_by_kernel) {
       float* sp = stats->p; const int ld = stats->ld, rows = p.M, C = p.N, ldy = p.ldy; const f16* y = p.y;
       push([=](hipStream_t s) { return row_stats(sp, ld, y, ldy, rows, C, s); }, "row_stats", 0, 2.0 * rows * C,
@@ -609,6 +637,7 @@ struct Builder {
     }
   }
 
+  std::vector<T> mx_tmp;
   RowStats alloc_stats(int rows, int c) {
     RowStats st;
     st.ld = std::max(1, (c + 31) / 32);          // narrowest epilogue strip is 32 columns
@@ -1265,6 +1294,7 @@ int sdeo_destroy(sdeo_handle h) {
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->wslab) (void)hipFree(h->wslab);
   if (h->q8slab) (void)hipFree(h->q8slab);
+  if (h->mxslab) (void)hipFree(h->mxslab);
   if (h->stage) (void)hipFree(h->stage);
   delete h;
   return 0;
@@ -1358,10 +1388,43 @@ int sdeo_finalize_weights(sdeo_handle h) {
       if (int rc = row_sums_f16(reinterpret_cast<float*>(h->wslab + f.s_out), reinterpret_cast<const f16*>(h->wslab + f.w_out), f.rows, f.C, 0))
         return rc;
   }
+  if (h->act_bits == 8) {
+    // block-scaled packs of every Linear / conv1x1 matrix whose K is a multiple of 128 (from the values the fp16 copies hold now,
+    // i.e. after the per-row fp8 rounding when weight_bits == 8)
+    if (!h->mxslab) {
+      size_t sz = 0;
+      for (const QRegion& q : h->qregions) {
+        if (q.cols % 128) continue;
+        sdeo_handle_s::MxRegion m{};
+        m.rows = q.rows; m.cols = q.cols;
+        m.q_off = align_up(sz, 256); sz = m.q_off + (size_t)q.rows * q.cols;
+        m.s_off = align_up(sz, 256); sz = m.s_off + (size_t)q.rows * (q.cols / 32);
+        h->mxindex[q.off] = m;
+      }
+      h->mx_bytes = align_up(sz, 256);
+      SDEO_HIP(hipMalloc((void**)&h->mxslab, h->mx_bytes < 256 ? 256 : h->mx_bytes));
+      h->device_bytes += h->mx_bytes;
+    }
+    for (auto& kv : h->mxindex)
+      if (int rc = quantize_mx(reinterpret_cast<uint8_t*>(h->mxslab + kv.second.q_off), reinterpret_cast<uint8_t*>(h->mxslab + kv.second.s_off),
+                               reinterpret_cast<const f16*>(h->wslab + kv.first), kv.second.rows, kv.second.cols, kv.second.cols, kv.second.cols,
+                               kv.second.cols / 32, 0))
+        return rc;
+  }
   SDEO_HIP(hipDeviceSynchronize());
   h->finalized = true;
   return 0;
 }
+
+int sdeo_set_activation_precision(sdeo_handle h, int bits, int min_rows) {
+  SDEO_CHECK(h, "sdeo_set_activation_precision: null handle");
+  SDEO_CHECK(bits == 16 || bits == 8, "sdeo_set_activation_precision: %d bits unsupported (16 or 8)", bits);
+  SDEO_CHECK(!h->finalized && !h->arena, "sdeo_set_activation_precision: call it before sdeo_finalize_weights / sdeo_configure");
+  h->act_bits = bits;
+  h->mx_min_rows = min_rows > 0 ? min_rows : 2048;
+  return 0;
+}
+int sdeo_debug_mx_launches(sdeo_handle h) { return h ? h->mx_launches : -1; }
 
 int sdeo_set_weight_precision(sdeo_handle h, int bits) {
   SDEO_CHECK(h, "sdeo_set_weight_precision: null handle");
@@ -1379,7 +1442,8 @@ int sdeo_configure(sdeo_handle h, int n, int latent_h, int latent_w) {
              "sdeo_configure: latent %dx%d must be a positive multiple of %d", latent_h, latent_w, maxds);
   SDEO_CHECK(h->weight_bits != 8 || h->q8slab, "sdeo_configure: fp8 weights are packed by sdeo_finalize_weights: call it first");
   free_configured(h);
-  h->device_bytes = h->wslab_bytes + h->q8_bytes;
+  h->device_bytes = h->wslab_bytes + h->q8_bytes + h->mx_bytes;
+  h->mx_launches = 0;
   h->N = n; h->lh = latent_h; h->lw = latent_w;
   const sdeo_config& c = h->cfg;
   const size_t px = (size_t)latent_h * latent_w;

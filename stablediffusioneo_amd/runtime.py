@@ -36,7 +36,7 @@ class SdeoRuntime:
     """create -> load_state_dict -> configure(n, h, w) -> controlnet / unet / apply_model / vae_decode."""
 
     def __init__(self, ucfg: S.UNetConfig = S.UNET_SD15, vcfg: S.VAEConfig = S.VAE_SD15, device: Optional[torch.device] = None,
-                 weight_bits: int = 16):
+                 weight_bits: int = 16, act_bits: int = 16, mx_min_rows: int = 0):
         """weight_bits = 8: the UNet / ControlNet matrices are packed to fp8 (OCP e4m3fn, per-output-channel power-of-two scale) when
         the weights are finalised (BASELINE configs[4]; the reference's precision switch is `onnx2trt_static_plugin.py:40-42`)."""
         if not torch.cuda.is_available():
@@ -51,6 +51,10 @@ class SdeoRuntime:
         self.weight_bits = int(weight_bits)
         if self.weight_bits != 16:
             check(self.lib.sdeo_set_weight_precision(self.handle, C.c_int(self.weight_bits)), "set_weight_precision")
+        # act_bits = 8: the GEMMs of >= mx_min_rows rows (default 2048) run block-scaled fp8 x fp8 on the fp8 MFMA (sdeo.h)
+        self.act_bits = int(act_bits)
+        if self.act_bits != 16:
+            check(self.lib.sdeo_set_activation_precision(self.handle, C.c_int(self.act_bits), C.c_int(int(mx_min_rows))), "set_activation_precision")
         self.n = self.h = self.w = 0
         self.n_controls = 13
         # bumped by every sdeo_configure: the library frees and re-plans its arenas / boundary buffers there, so a hipGraph

@@ -37,7 +37,7 @@ def test_mx_pack_matches_oracle():
         assert torch.equal(q.cpu(), q0), f"codes differ in {int((q.cpu() != q0).sum())} places"
 
 
-MX_TILES = [0, 1, 6, 7, 21]
+MX_TILES = [0, 1, 6, 21]
 
 
 @pytest.mark.parametrize("tile", MX_TILES)
