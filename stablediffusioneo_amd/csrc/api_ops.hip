@@ -126,6 +126,23 @@ int sdeo_conv2d_nhwc_f16(void* y, const void* x, const void* w_krsc, const float
   return conv_gemm(p, S(stream));
 }
 
+// conv3x3 that applies GroupNorm(groups = 32) (+ SiLU) of its INPUT itself (ConvGemm::gn_in) from per-(image, slot, group) partial
+// (sum, sumsq) of x.  *ok = 0 when the plan of this shape cannot (nothing is launched then).
+int sdeo_debug_conv2d_gnin_f16(void* y, const void* x, const void* w_krsc, const float* bias, int n, int h, int w, int cin, int cout,
+                               const float* gamma, const float* beta, const float* partials, int slots, float eps, int with_silu,
+                               void* workspace, size_t workspace_bytes, int* ok, void* stream) {
+  (void)disarm_fp8();
+  SDEO_CHECK(ok && partials && gamma && beta, "conv2d_gnin: null argument");
+  ConvGemm p;
+  if (int rc = fill_conv(p, n, h, w, cin, cout, 3, 1, 0)) return rc;
+  p.x = (const f16*)x; p.w = (const f16*)w_krsc; p.y = (f16*)y; p.bias = bias;
+  p.workspace = (float*)workspace; p.workspace_bytes = workspace_bytes;
+  *ok = conv_gemm_gn_in_ok(p) ? 1 : 0;
+  if (!*ok) return 0;
+  p.gn_in = partials; p.gn_in_slots = slots; p.gn_gamma = gamma; p.gn_beta = beta; p.gn_in_eps = eps; p.gn_in_silu = with_silu;
+  return conv_gemm(p, S(stream));
+}
+
 // conv2d whose epilogue emits the GroupNorm partials of its output, followed by the normalise-only GroupNorm that consumes them
 // (the [conv -> GroupNorm] pairs of the networks, csrc/net.hip).  *slots = entries per image the plan writes; 0 = this shape's plan
 // cannot emit them (nothing is launched then).  partials >= n * slots * groups * 2 floats (+ n * groups * 2 when slots > 128).

@@ -914,6 +914,15 @@ bool conv_gemm_plan_is_halo(const ConvGemm& p) { return kTiles[make_plan(mx_view
 // GroupNorm partials from the epilogue (KP::gn_out): entries per image the plan of p writes for groups of `cpg` channels, or 0 when it
 // cannot (split-K, a strip that cuts a group, a tile that straddles two images, the register-staged fallback kernel, an epilogue
 // that is not the LDS-transposed one)
+bool conv_gemm_gn_in_ok(const ConvGemm& p) {
+  if (p.mx_sx || p.Cin % 32 || p.R != 3) return false;
+  const Plan pl = make_plan(p);
+  const TileCfg& c = kTiles[pl.tile];
+  if (c.kind != TK_HALO || !halo_ok(p, c)) return false;
+  const int per = cdiv(pl.nk, pl.splitk);
+  return per <= 32 && halo_ring_bytes(c.stages) + per * 512 <= 160 * 1024;      // (the MFMA waves build the table 2048 channels at a time)
+}
+
 static int gn_slots_of(const ConvGemm& p, int cpg);
 int conv_gemm_gn_slots(const ConvGemm& p0, int cpg) { return gn_slots_of(mx_view(p0), cpg); }
 static int gn_slots_of(const ConvGemm& p, int cpg) {       // p: the view the kernels see (mx_view)
@@ -1041,6 +1050,13 @@ static int prepare(const ConvGemm& p, Plan& pl, KP& kp) {
     SDEO_CHECK(strips >= 1 && p.stats_ld >= strips && p.y && !p.y32 && p.act != 3,
                "conv_gemm: row statistics need an unsplit fp16 plan (strips %d, stats_ld %d)", strips, p.stats_ld);
     kp.stats_out = p.stats_out; kp.stats_ld = p.stats_ld;
+  }
+  if (p.gn_in) {
+    SDEO_CHECK(p.gn_gamma && p.gn_beta && p.gn_in_slots >= 1 && conv_gemm_gn_in_ok(p),
+               "conv_gemm: GroupNorm of the input needs a halo-reuse 3x3 plan with LDS left for its table");
+    kp.gn_in = p.gn_in; kp.gn_gamma = p.gn_gamma; kp.gn_beta = p.gn_beta; kp.gn_in_slots = p.gn_in_slots;
+    kp.gn_in_cpg = p.Cin / 32; kp.gn_in_silu = p.gn_in_silu; kp.gn_in_eps = p.gn_in_eps;
+    kp.gn_in_inv = 1.0f / ((float)(p.Cin / 32) * (float)p.Hi * (float)p.Wi);
   }
   if (p.gn_out) {
     const int slots = gn_slots_of(p, p.gn_cpg);
@@ -1236,6 +1252,7 @@ int conv_gemm_autotune(const ConvGemm& p, hipStream_t stream) {
       q.force_tile = t;
       q.force_splitk = sk;
       q.gn_out = nullptr;                              // candidates are timed without the GroupNorm partials (not every plan can emit them)
+      q.gn_in = nullptr;
       if (int rc = conv_gemm(q, stream)) return rc;    // warm-up (also sets the function attributes)
       // best of two rounds of 8 back-to-back launches: single short rounds flipped plans from run to run
       const int reps = 8;

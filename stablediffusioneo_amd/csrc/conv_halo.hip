@@ -130,9 +130,58 @@ __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP2 
     // a "step" of the loaders is one ring slot = TPB taps; SPS steps per Cin slice
     constexpr int SPS = 9 / TPB, LWS = LW * TPB;
     const int lsteps = nsteps / TPB;
+    // ---- GroupNorm (+ SiLU) of the input (KP::gn_in): every piece (16 bytes = 8 channels of one halo pixel) this lane staged is
+    //      rewritten in place once its DMA has landed.  The lane's logical channel chunk is the same for all its pieces
+    //      ((hr >> 1) & 7 does not depend on the piece index), so one (a, b) set per slice serves them all.  All LDS traffic of the
+    //      loaders is inline asm: the compiler must not see LDS accesses next to LDS-DMAs (it would wait vmcnt(0) for them).
+    const bool gnin = p.gn_in != nullptr;
+    const int clq = pc ^ ((lw * 4 + (lrow >> 1)) & 7);
+    const unsigned ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned tab0 = ldsb + 2 * XBYTES + WST * TPB * WBYTES + clq * 64;      // (a, b) pairs of this lane's chunk, slice 0
+    auto transform = [&](int buf, int slice_rel, int qa, int qb) {
+      f32x4 t0, t1, t2, t3;
+      const unsigned ta = tab0 + slice_rel * 512;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(t0) : "v"(ta) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(t1) : "v"(ta) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(t2) : "v"(ta) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:48" : "=v"(t3) : "v"(ta) : "memory");
+      const unsigned xb = ldsb + buf * XBYTES + lw * 1024 + lane * 16;
+      f16x8 v[LXW];
+#pragma unroll
+      for (int q = 0; q < LXW; ++q)
+        if (q >= qa && q < qb && xinc[q]) asm volatile("ds_read_b128 %0, %1" : "=v"(v[q]) : "v"(xb + q * 4096) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3) : : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      const float av[8] = {t0[0], t0[2], t1[0], t1[2], t2[0], t2[2], t3[0], t3[2]};
+      const float bv[8] = {t0[1], t0[3], t1[1], t1[3], t2[1], t2[3], t3[1], t3[3]};
+#pragma unroll
+      for (int q = 0; q < LXW; ++q) {
+        if (q >= qa && q < qb && xinc[q]) {
+          asm volatile("" : "+v"(v[q]));
+          f16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float f = fmaf((float)v[q][j], av[j], bv[j]);
+            if (p.gn_in_silu) f = silu_f(f);
+            o[j] = (f16)f;
+          }
+          asm volatile("ds_write_b128 %0, %1" : : "v"(xb + q * 4096), "v"(o) : "memory");
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    // the (a, b) loads of a transform and the pieces it rewrites: TPB = 3: half of them at step 1, half at step 2 of the previous
+    // slice; TPB = 1: one piece per step from step 2 on
+    constexpr int TR0 = TPB == 3 ? 1 : 2;               // first step of a slice that transforms the NEXT slice's patch
+    int wsince = 0;                                     // W stages issued since the last patch (they are younger than it)
     issue_x(0);
 #pragma unroll
     for (int s = 0; s < PF; ++s) issue_w(s);           // lsteps >= SPS > PF
+    if (gnin) {
+      __builtin_amdgcn_s_barrier();                    // T: the MFMA waves have built the (a, b) table
+      wait_vmcnt<PF * LWS>();                          // patch 0 has landed (the PF weight stages behind it may still fly)
+      transform(0, 0, 0, LXW);
+    }
     int tap = 0, cr = 0;                               // step inside the slice / relative Cin slice of step `it`
     const int ncr = c1 - c0;
     for (int it = 0; it < lsteps; ++it) {
@@ -152,8 +201,23 @@ __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP2 
       __builtin_amdgcn_s_barrier();
       // every MFMA wave now holds step it-1 in registers: its W slot and (at step 0) the previous slice's patch are free
       if (dbg_on(p, 8)) { if (++tap == SPS) { tap = 0; ++cr; } continue; }      // SDEO_DBG_GEMM ablation: no DMAs after the prologue
-      if (tap == 0 && cr + 1 < ncr) issue_x((cr + 1) & 1);
-      if (it + PF < lsteps) issue_w((it + PF) % WST);
+      if (tap == 0 && cr + 1 < ncr) { issue_x((cr + 1) & 1); wsince = 0; }
+      if (it + PF < lsteps) { issue_w((it + PF) % WST); ++wsince; }
+      if (gnin && cr + 1 < ncr && tap >= TR0) {
+        // the next slice's patch, issued at step 0 of this slice: it must have landed; only the weight stages issued since may fly
+        if (tap == TR0) {
+          static_for<TR0 + 2>([&](auto A) {
+            if (wsince == A.value) wait_vmcnt<A.value * LWS>();
+          });
+        }
+        if (TPB == 3) {
+          if (tap == 1) transform((cr + 1) & 1, cr + 1, 0, LXW / 2);
+          else transform((cr + 1) & 1, cr + 1, LXW / 2, LXW);
+        } else {
+          const int q = tap - TR0;
+          if (q < LXW) transform((cr + 1) & 1, cr + 1, q, q + 1);
+        }
+      }
       if (++tap == SPS) { tap = 0; ++cr; }
     }
     __builtin_amdgcn_s_barrier();            // matches the MFMA waves' pre-epilogue barrier
@@ -177,6 +241,53 @@ __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP2 
   for (int i = 0; i < NI; ++i) {
     const int n = n0 + i * 16 + fq * 4;
     bpre[i] = (use_bpre && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  if (p.gn_in && nsteps > 0) {
+    // (a, b) of every channel of this workgroup's range for its image: each wave sums the producer's partials of all 32 groups
+    // (lane pair = group, fixed order: deterministic), then takes its share of the channels; the group of a channel is fetched
+    // from the lane that holds it.  Runs while the loaders' first DMAs are in flight.
+    // every load of this block is issued before the first use (one memory round trip instead of three dependent ones): gamma / beta
+    // of this lane's channels first, then the partials of its group
+    constexpr int CPL = 8;                                // channels per lane: covers (c1 - c0) * 64 <= NMW * 64 * CPL
+    const int nchan = (c1 - c0) * 64;
+    float gam[CPL], bet[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int cc = wave * 64 + lane + k * NMW * 64;
+      const int ch = c0 * 64 + (cc < nchan ? cc : 0);
+      gam[k] = p.gn_gamma[ch];
+      bet[k] = p.gn_beta[ch];
+    }
+    const int g = lane >> 1, half = lane & 1;
+    const float2* src = reinterpret_cast<const float2*>(p.gn_in) + ((size_t)b * p.gn_in_slots) * 32 + g;
+    float ts = 0.f, tq = 0.f;
+    for (int s0 = half; s0 < p.gn_in_slots; s0 += 32) {
+      float2 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = s0 + 2 * u < p.gn_in_slots ? src[(size_t)(s0 + 2 * u) * 32] : make_float2(0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { ts += v[u].x; tq += v[u].y; }
+    }
+    const float os = __shfl_xor(ts, 1, 64), oq = __shfl_xor(tq, 1, 64);
+    const float s_all = half ? os + ts : ts + os, q_all = half ? oq + tq : tq + oq;      // half 0 + half 1 in both lanes
+    const float mean = s_all * p.gn_in_inv;
+    float var = q_all * p.gn_in_inv - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    const float rstd = rsqrtf(var + p.gn_in_eps);
+    float* tab = reinterpret_cast<float*>(smem + 2 * XBYTES + WST * TPB * WBYTES);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int cc = wave * 64 + lane + k * NMW * 64;       // whole waves are inside or outside the range (nchan % 64 == 0)
+      if (cc < nchan) {
+        const int gg = (c0 * 64 + cc) / p.gn_in_cpg;
+        const float m_ = __shfl(mean, 2 * gg, 64), r_ = __shfl(rstd, 2 * gg, 64);
+        const float a_ = r_ * gam[k];
+        *reinterpret_cast<float2*>(tab + 2 * cc) = make_float2(a_, bet[k] - m_ * a_);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // T: table visible to the loader waves
   }
 
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -324,13 +435,24 @@ static int launch_halo_t(const KP2& kp, int count, int tiles_m, int tiles_n, hip
   static DeviceOnce done;
   if (done.need()) {
     SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<PH, PW, BN, NMW, TPB>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done.mark();
   }
-  hipLaunchKernelGGL((conv3x3_halo_kernel<PH, PW, BN, NMW, TPB>), dim3(tiles_m * tiles_n, count, kp.k[0].splitk), dim3(NMW * 64 + 256), smem, stream,
+  // GroupNorm of the input (KP::gn_in): the (a, b) table of the workgroup's channel range sits behind the ring
+  const int extra = kp.k[0].gn_in ? kp.k[0].nk_per_split * 512 : 0;
+  SDEO_CHECK(smem + extra <= 160 * 1024, "conv3x3_halo_kernel: no LDS left for the GroupNorm table (%d + %d bytes)", smem, extra);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<PH, PW, BN, NMW, TPB>), dim3(tiles_m * tiles_n, count, kp.k[0].splitk), dim3(NMW * 64 + 256), smem + extra, stream,
                      kp);
   SDEO_HIP(hipGetLastError());
   return 0;
+}
+
+// LDS the ring of a variant takes (what is left of 160 KiB can hold the GroupNorm table of KP::gn_in)
+int halo_ring_bytes(int variant) {
+  static const int tpb[] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 3, 3, 3, 3, 3, 3, 3};
+  if (variant < 0 || variant >= kNumHaloCfgs) return 1 << 30;
+  const HaloCfg& h = kHaloCfgs[variant];
+  return 2 * halo_xbytes(h.ph, h.pw) + halo_stages(h.ph, h.pw, h.bn, tpb[variant]) * tpb[variant] * halo_wbytes(h.bn);
 }
 
 int launch_halo(int variant, const KP2& kp, int count, int tiles_m, int tiles_n, hipStream_t stream) {

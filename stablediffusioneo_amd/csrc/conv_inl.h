@@ -50,6 +50,16 @@ struct KP {
   //      the consumer sums the gn_slots entries of a group in a fixed order (deterministic, no atomics).
   float* gn_out;           // [B][gn_slots][gn_groups][2]; null = off
   int gn_cpg, gn_slots, gn_groups;
+  // ---- consumer side, GroupNorm (+ SiLU) of the INPUT (conv3x3_halo_kernel): x is the raw tensor, gn_in the partials its producer's
+  //      epilogue wrote (gn_out of that launch).  The MFMA waves turn them into per-channel (a, b) = (rstd gamma, beta - mean rstd gamma) of
+  //      the workgroup's image and channel range in LDS while the first DMAs fly; the loader waves rewrite every staged patch in place
+  //      (y = silu(a x + b), padding left at zero) before the barrier that shows it to the MFMA waves: no GroupNorm launch, no
+  //      normalised copy of the tensor in memory.
+  const float* gn_in;       // [B][gn_in_slots][32][2]; null = off
+  const float* gn_gamma;    // [Cin]
+  const float* gn_beta;     // [Cin]
+  int gn_in_slots, gn_in_cpg, gn_in_silu;
+  float gn_in_eps, gn_in_inv;   // 1 / (cpg * H * W)
   // ---- block-scaled fp8 operands (conv_gemm_dma_kernel<..., MX>, GEMM only): x and w hold OCP e4m3fn codes (one byte per element,
   //      addressed through this block as fp16 arrays of half the length: K, Cin, ldx, ldw count PAIRS of codes), mx_sx / mx_sw one
   //      e8m0 scale byte per 32 codes of a row.  The MFMA is v_mfma_scale_f32_16x16x128_f8f6f4: 128 codes per K-step.
@@ -592,5 +602,6 @@ struct HaloCfg { int ph, pw, bn; const char* name; };
 extern const HaloCfg kHaloCfgs[];
 extern const int kNumHaloCfgs;
 int launch_halo(int variant, const KP2& kp, int count, int tiles_m, int tiles_n, hipStream_t stream);
+int halo_ring_bytes(int variant);
 
 }  // namespace sdeo

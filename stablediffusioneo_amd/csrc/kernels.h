@@ -50,6 +50,13 @@ struct ConvGemm {
   // group over the rows of one M tile of image b; gn_slots must equal conv_gemm_gn_slots(p, gn_cpg) (> 0)
   float* gn_out = nullptr;
   int gn_cpg = 0, gn_slots = 0, gn_groups = 0;
+  // GroupNorm(32 groups) + optional SiLU of the INPUT applied inside the conv (halo-reuse 3x3 kernels only, conv_gemm_gn_in_ok):
+  // x is the raw tensor, gn_in the partials the producer of x emitted ([B][gn_in_slots][32][2], ConvGemm::gn_out of that launch)
+  const float* gn_in = nullptr;
+  const float* gn_gamma = nullptr;
+  const float* gn_beta = nullptr;
+  int gn_in_slots = 0, gn_in_silu = 0;
+  float gn_in_eps = 1e-5f;
   // block-scaled fp8 GEMM (both operands OCP e4m3fn codes + one e8m0 scale byte per 32 codes of a row, quantize_mx): x and w point at
   // BYTES, K / ldx / ldw count codes, K % 128 == 0, R = S = 1.  Runs on v_mfma_scale_f32_16x16x128_f8f6f4.
   const uint8_t* mx_sx = nullptr;  // [M][mx_ldsx]
@@ -59,6 +66,9 @@ struct ConvGemm {
 int conv_gemm(const ConvGemm& p, hipStream_t stream);
 // M tiles per image of the plan chosen for p when its epilogue can emit GroupNorm partials for groups of cpg channels, else 0
 int conv_gemm_gn_slots(const ConvGemm& p, int cpg);
+// whether the plan chosen for p can apply a GroupNorm(32) of its input itself (ConvGemm::gn_in): a halo-reuse 3x3 kernel with LDS left
+// for the (a, b) table of a workgroup's channel range
+bool conv_gemm_gn_in_ok(const ConvGemm& p);
 // whether the plan chosen for p is a halo-reuse 3x3 kernel (which has no fp8-weight variant)
 bool conv_gemm_plan_is_halo(const ConvGemm& p);
 // strips (partials per row) a launch of p writes to stats_out; 0 when the chosen plan cannot emit them (split-K)
@@ -97,6 +107,8 @@ struct GnArgs {
   const float* ext_partials = nullptr;
   int ext_nsc = 0;
 };
+// out[b][g] = sum over the nsc entries of in[b][.][g] (fixed order): producer-side partials of a large image folded to one entry per group
+int groupnorm_fold_partials(float* out, const float* in, int B, int nsc, int groups, hipStream_t stream);
 // whether groupnorm_nhwc(a) runs as ONE launch with its slice in LDS
 bool groupnorm_is_single_launch(const GnArgs& a);
 int groupnorm_nhwc(const GnArgs& a, hipStream_t stream);

@@ -502,6 +502,9 @@ struct ConvOpts {                     // conv / gemm options
   const RowStats* ln = nullptr;  // consumer: LayerNorm folded into this GEMM, statistics of x from *ln, row sums ln_s
   const float* ln_s = nullptr;
   bool gn_next = false;          // the output feeds a GroupNorm(32): let the epilogue emit its partial statistics when the plan can
+  // GroupNorm(32) (+ SiLU) of the conv's INPUT applied inside the conv kernel (Builder::gn_conv decides): the partials of x, gamma / beta
+  const float* gn_in = nullptr; int gn_in_slots = 0; const float* gn_gamma = nullptr; const float* gn_beta = nullptr;
+  float gn_in_eps = 1e-5f; int gn_in_silu = 0;
 };
 
 struct Builder {
@@ -674,6 +677,10 @@ struct Builder {
     p.B = x.n; p.Hi = x.h; p.Wi = x.w; p.Cin = x.c; p.Ho = ho; p.Wo = wo; p.R = p.S = k; p.stride = stride; p.pad = pad; p.ups = ups;
     p.M = x.n * ho * wo; p.N = cs; p.K = k * k * x.c;
     p.ldx = x.ld; p.ldw = p.K; p.ldy = y.ld; p.act = o.act;
+    if (o.gn_in) {
+      p.gn_in = o.gn_in; p.gn_in_slots = o.gn_in_slots; p.gn_gamma = o.gn_gamma; p.gn_beta = o.gn_beta; p.gn_in_eps = o.gn_in_eps;
+      p.gn_in_silu = o.gn_in_silu;
+    }
     const bool want_gn = o.gn_next && !o.out && !o.scale_host && cs == y.c;
     if (want_gn) reserve_gn_partials(p, y);
     launch_conv(p, o.scale_host, o.stats, want_gn ? &y : nullptr);
@@ -738,6 +745,43 @@ struct Builder {
     return y;
   }
 
+  // conv3x3(act(GroupNorm(x))) (`openaimodel.py:255-275`, `model.py:129-149`).  When x carries its producer's partials and the conv's
+  // plan is a halo-reuse kernel with LDS left for the (a, b) table, the conv applies the GroupNorm itself (KP::gn_in): no GroupNorm
+  // launch, no normalised copy.  Otherwise GroupNorm launch(es) + conv.
+  static bool gn_in_enabled() { static const bool on = [] { const char* v = getenv("SDEO_GN_IN_CONV"); return !v || atoi(v) != 0; }(); return on; }
+  T gn_conv(const T& x, const std::string& gn_name, float eps, int silu_, const std::string& conv_name, int cout, CO o) {
+    if (gn_in_enabled() && !e->autotune && x.gnp && x.gn_slots > 0 && x.c % 32 == 0) {
+      ConvGemm q;
+      const int cs = o.cout_store > 0 ? o.cout_store : cout;
+      q.B = x.n; q.Hi = x.h; q.Wi = x.w; q.Cin = x.c; q.Ho = x.h; q.Wo = x.w; q.R = q.S = 3; q.stride = 1; q.pad = 1;
+      q.M = x.n * x.h * x.w; q.N = cs; q.K = 9 * x.c; q.ldx = x.ld; q.ldw = q.K; q.ldy = cs; q.act = o.act;
+      if (x.ld == x.c && conv_gemm_gn_in_ok(q)) {
+        const float* part = x.gnp;
+        int slots = x.gn_slots;
+        T folded;
+        if (slots > 128) {               // large images (VAE): fold the entries of a group first, the conv's prologue sums few
+          folded = alloc2d(x.n, 32 * 2 * 2);            // [n][1][32][2] floats
+          float* fp = reinterpret_cast<float*>(folded.p);
+          const int B = x.n, ns = slots;
+          push([=](hipStream_t s) { return groupnorm_fold_partials(fp, part, B, ns, 32, s); }, "groupnorm", 0, 0, "fold " + std::to_string(ns));
+          part = fp;
+          slots = 1;
+        }
+        o.gn_in = part; o.gn_in_slots = slots; o.gn_gamma = vptr(gn_name + ".weight"); o.gn_beta = vptr(gn_name + ".bias");
+        o.gn_in_eps = eps; o.gn_in_silu = silu_;
+        T y = conv(x, conv_name, cout, 3, 1, 0, o);
+        if (slots == 1 && folded.off != (size_t)-1) release(folded);
+        ++gn_in_fused;
+        return y;
+      }
+    }
+    T t = gn(x, gn_name, eps, silu_);
+    T y = conv(t, conv_name, cout, 3, 1, 0, o);
+    release(t);
+    return y;
+  }
+  int gn_in_fused = 0;
+
   T ln(const T& x, const std::string& name) {
     T y = alloc(x.n, x.h, x.w, x.c);
     const float* g = vptr(name + ".weight");
@@ -760,15 +804,11 @@ struct Builder {
 // ResBlock._forward (`openaimodel.py:255-275`)
 static T build_res(Builder& b, const std::string& ns, const Blk& blk, const T& x, const float* emb_all, int emb_ld, const T* out = nullptr) {
   const std::string p = ns + blk.name;
-  T t1 = b.gn(x, p + ".in_layers.0", 1e-5f, 1);
   Builder::CO o1;
   o1.bias2 = emb_all + b.e->emb_row.at(p);
   o1.ld_bias2 = emb_ld;
   o1.gn_next = true;
-  T h1 = b.conv(t1, p + ".in_layers.2", blk.cout, 3, 1, 0, o1);
-  b.release(t1);
-  T t2 = b.gn(h1, p + ".out_layers.0", 1e-5f, 1);
-  b.release(h1);
+  T h1 = b.gn_conv(x, p + ".in_layers.0", 1e-5f, 1, p + ".in_layers.2", blk.cout, o1);
   T skip;
   const T* res = &x;
   if (blk.cin != blk.cout) {
@@ -779,8 +819,8 @@ static T build_res(Builder& b, const std::string& ns, const Blk& blk, const T& x
   o2.res = res;
   o2.out = out;
   o2.gn_next = true;
-  T y = b.conv(t2, p + ".out_layers.3", blk.cout, 3, 1, 0, o2);
-  b.release(t2);
+  T y = b.gn_conv(h1, p + ".out_layers.0", 1e-5f, 1, p + ".out_layers.3", blk.cout, o2);
+  b.release(h1);
   if (blk.cin != blk.cout) b.release(skip);
   return y;
 }
@@ -1092,11 +1132,9 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
         cat = ncat;
       } else {
         T y = run_blocks(ns, blocks, cat, true, emb_all, e->emb_total[0], 0, nullptr);
-        T g = b.gn(y, ns + "out.0", 1e-5f, 1);
-        b.release(y);
         Builder::CO oo; oo.cout_store = 4 * ((c.out_channels + 3) / 4);
-        T eps = b.conv(g, ns + "out.2", c.out_channels, 3, 1, 0, oo);
-        b.release(g);
+        T eps = b.gn_conv(y, ns + "out.0", 1e-5f, 1, ns + "out.2", c.out_channels, oo);
+        b.release(y);
         {
           float* o = e->out_eps; const f16* in = eps.p; const int ld = eps.ld, Cc = c.out_channels, HW = h * w;
           b.push([=](hipStream_t s) { return nhwc_f16_to_nchw_f32(o, in, ld, N, Cc, HW, 1.0f, s); });
@@ -1126,16 +1164,12 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
     T hcur = b.conv(z2, d + ".conv_in", bin, 3, 1, 0, gnx);
     b.release(z2);
     auto vres = [&](const std::string& p, const T& x, int cin, int cout) {
-      T t1 = b.gn(x, p + ".norm1", 1e-6f, 1);
-      T h1 = b.conv(t1, p + ".conv1", cout, 3, 1, 0, gnx);
-      b.release(t1);
-      T t2 = b.gn(h1, p + ".norm2", 1e-6f, 1);
-      b.release(h1);
+      T h1 = b.gn_conv(x, p + ".norm1", 1e-6f, 1, p + ".conv1", cout, gnx);
       T sk; const T* res = &x;
       if (cin != cout) { sk = b.conv(x, p + ".nin_shortcut", cout, 1, 1, 0); res = &sk; }
       Builder::CO o; o.res = res; o.gn_next = true;
-      T y = b.conv(t2, p + ".conv2", cout, 3, 1, 0, o);
-      b.release(t2);
+      T y = b.gn_conv(h1, p + ".norm2", 1e-6f, 1, p + ".conv2", cout, o);
+      b.release(h1);
       if (cin != cout) b.release(sk);
       return y;
     };
@@ -1201,11 +1235,9 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
         hcur = y;
       }
     }
-    T g = b.gn(hcur, d + ".norm_out", 1e-6f, 1);
-    b.release(hcur);
     Builder::CO oo; oo.cout_store = 4 * ((c.vae_out_ch + 3) / 4);
-    T img = b.conv(g, d + ".conv_out", c.vae_out_ch, 3, 1, 0, oo);
-    b.release(g);
+    T img = b.gn_conv(hcur, d + ".norm_out", 1e-6f, 1, d + ".conv_out", c.vae_out_ch, oo);
+    b.release(hcur);
     {
       float* o = e->vae_out; uint8_t* u8 = e->vae_u8; const f16* in = img.p; const int ld = img.ld, Cc = c.vae_out_ch, HW = 64 * h * w;
       b.push([=](hipStream_t s) {

@@ -260,6 +260,14 @@ __global__ __launch_bounds__(256) void gn_fold_partials_kernel(float2* __restric
   if (tid == 0) out[(size_t)b * groups + g] = red[0];
 }
 
+int groupnorm_fold_partials(float* out, const float* in, int B, int nsc, int groups, hipStream_t stream) {
+  SDEO_CHECK(out && in && B > 0 && nsc > 0 && groups > 0, "groupnorm_fold_partials: bad argument");
+  hipLaunchKernelGGL(gn_fold_partials_kernel, dim3(B * groups), dim3(256), 0, stream, reinterpret_cast<float2*>(out),
+                     reinterpret_cast<const float2*>(in), nsc, groups);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Single-launch GroupNorm for tensors whose per-(image, group set) slice fits in one workgroup's LDS.
 // Every kernel on this chip costs ~4 us of launch + dependent round trips whatever its size (DESIGN.md

@@ -33,6 +33,11 @@ int sdeo_debug_gemm_stats_f16(void* y, int ldy, const void* x, int ldx, const vo
 int sdeo_debug_gemm_ln_f16(void* y, int ldy, const void* x, int ldx, const void* w_folded, int ldw, const float* ln_s,
                            const float* bias_folded, const float* stats, int stats_ld, int strips, int ln_c, int m, int n, int k, int act, float eps, void* workspace, size_t workspace_bytes, void* stream);
 int sdeo_debug_row_stats_f16(float* stats, int stats_ld, const void* x, int ldx, int rows, int c, void* stream);
+/* conv3x3 with GroupNorm(32) (+ SiLU) of its input applied inside the kernel from partial (sum, sumsq) [n][slots][32][2] of x;
+ * *ok = 0: the plan of this shape cannot (nothing ran) */
+int sdeo_debug_conv2d_gnin_f16(void* y, const void* x, const void* w_krsc, const float* bias, int n, int h, int w, int cin, int cout,
+                               const float* gamma, const float* beta, const float* partials, int slots, float eps, int with_silu,
+                               void* workspace, size_t workspace_bytes, int* ok, void* stream);
 /* [conv whose epilogue emits the GroupNorm partials of its output] -> [normalise-only GroupNorm]: the pair csrc/net.hip builds for
  * every conv that feeds a GroupNorm.  *slots = partial entries per image (0: this shape's plan cannot emit them, nothing ran);
  * partials >= n * slots * groups * 2 floats (+ n * groups * 2 when slots > 128) */

@@ -140,6 +140,23 @@ def conv2d_gn(x, w_krsc, gamma, beta, bias=None, res=None, stride=1, upsample2x=
     return y, yn, slots.value
 
 
+def conv3x3_gn_in(x, w_krsc, gamma, beta, partials, bias=None, eps=1e-5, swish=True):
+    """conv3x3(silu(GroupNorm32(x))) with the normalisation applied inside the conv kernel from `partials` [n][slots][32][2] = partial
+    (sum, sumsq) of x per (image, slot, group); None when the plan of this shape cannot."""
+    lib = _lib.load()
+    _need_cuda(x, w_krsc, gamma, beta, partials)
+    n, h, w, cin = x.shape
+    cout = w_krsc.shape[0]
+    assert x.is_contiguous() and w_krsc.is_contiguous() and partials.dtype == torch.float32 and partials.is_contiguous()
+    y = torch.empty((n, h, w, cout), dtype=torch.float16, device=x.device)
+    ws = _ws(64 << 20, x.device)
+    ok = C.c_int(0)
+    check(lib.sdeo_debug_conv2d_gnin_f16(ptr(y), ptr(x), ptr(w_krsc), ptr(bias), _i(n), _i(h), _i(w), _i(cin), _i(cout), ptr(gamma), ptr(beta),
+                                         ptr(partials), _i(partials.shape[1]), _f(eps), _i(int(swish)), ptr(ws), C.c_size_t(ws.numel()),
+                                         C.byref(ok), cur_stream()), "conv3x3_gn_in")
+    return y if ok.value else None
+
+
 def gemm(x, w, bias=None, res=None, act=0, scale=1.0, out_f32=False, bias_per_row=False, w8=None):
     """y[m][n] = x[m][k] . w[n][k]^T (+bias)(+res); x, w fp16 row-major (may be strided views with unit inner stride).
     w8 = (codes, scales): stream the fp8 copy of w instead."""

@@ -88,3 +88,65 @@ def test_plans_that_cannot_emit_are_refused(ops):
     x8 = h16(randn((1, 32, 32, 8), 512)).to(DEV)             # Cin % 64 != 0: the fallback kernel
     w8 = h16(randn((320, 3, 3, 8), 513) * 0.1).to(DEV)
     assert ops.conv2d_gn(x8, w8, g, b) is None
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# consumer side: conv3x3(silu(GroupNorm(x))) with the GroupNorm applied inside the halo conv kernel (KP::gn_in): the loader waves
+# rewrite each staged patch in LDS, the statistics come as per-(image, slot, group) partials.  Reference: torch fp32 on the same fp16 x.
+# ---------------------------------------------------------------------------------------------------------------------------
+GNIN_CASES = [
+    (34, 1, 2, 320, 32, 32, 320, True),     # halo <8,16,80,4,3>: 5 slices, one barrier per filter row
+    (35, 1, 1, 320, 16, 32, 160, True),     # <8,16,80,8,3>
+    (37, 1, 2, 128, 16, 16, 80, False),     # <8,8,80,4,3>, no SiLU (SpatialTransformer.norm semantics)
+    (37, 4, 1, 1280, 16, 16, 640, True),    # split-K 4 over 20 slices: each workgroup builds the table of its own channel range
+    (13, 1, 2, 320, 16, 32, 320, True),     # one barrier per tap (TPB = 1): one piece per step
+    (22, 2, 1, 256, 16, 16, 128, True),     # <8,16,80,8>
+    (38, 1, 1, 320, 24, 8, 320, True),      # <8,8,160,4,3>
+]
+
+
+@pytest.mark.parametrize("case", GNIN_CASES)
+def test_conv_applies_groupnorm_of_its_input(ops, case):
+    from stablediffusioneo_amd import _lib
+    lib = _lib.load()
+    tile, sk, n, cin, h, w, cout, swish = case
+    x = h16(randn((n, h, w, cin), 600 + tile) * 1.3 + 0.4).to(DEV)
+    wt = h16(randn((cout, 3, 3, cin), 601) * (1.0 / (cin * 9)) ** 0.5).to(DEV)
+    bias = (0.1 * randn((cout,), 602)).to(DEV)
+    gamma = (1.0 + 0.3 * randn((cin,), 603)).to(DEV)
+    beta = (0.2 * randn((cin,), 604)).to(DEV)
+    # partials as a producer would leave them: 3 slots per image, each over a third of the rows
+    xf = x.float().reshape(n, h * w, 32, cin // 32)
+    cuts = [0, (h * w) // 3, (2 * h * w) // 3, h * w]
+    part = torch.stack([torch.stack([xf[:, cuts[i]:cuts[i + 1]].sum(dim=(1, 3)), (xf[:, cuts[i]:cuts[i + 1]] ** 2).sum(dim=(1, 3))], -1)
+                        for i in range(3)], 1).contiguous()                  # [n][3][32][2]
+    try:
+        lib.sdeo_debug_force_gemm_plan(C.c_int(tile), C.c_int(sk))
+        y = ops.conv3x3_gn_in(x, wt, gamma, beta, part, bias=bias, eps=1e-5, swish=swish)
+        y2 = ops.conv3x3_gn_in(x, wt, gamma, beta, part, bias=bias, eps=1e-5, swish=swish)
+    finally:
+        lib.sdeo_debug_force_gemm_plan(C.c_int(-1), C.c_int(0))
+    assert y is not None, f"{case}: the plan refused"
+    assert torch.equal(y, y2), "not deterministic"
+    t = F.group_norm(x.float().permute(0, 3, 1, 2), 32, gamma, beta, 1e-5)
+    t = F.silu(t) if swish else t
+    ref = F.conv2d(t.half().float(), wt.float().permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1)
+    err = (y.float() - ref).abs()
+    tol = 3e-3 * ref.abs() + 4e-3 * float(ref.abs().max())
+    assert bool((err <= tol).all()), f"{case}: max err {float(err.max()):.3e} at scale {float(ref.abs().max()):.3g}"
+
+
+def test_gn_in_is_refused_without_lds_for_the_table(ops):
+    """<8,16,80,8,3> leaves 4 KB of LDS beside its ring: ten 64-channel slices of (a, b) do not fit -- the networks then keep the
+    GroupNorm launch"""
+    from stablediffusioneo_amd import _lib
+    lib = _lib.load()
+    x = h16(randn((1, 16, 32, 640), 610)).to(DEV)
+    wt = h16(randn((160, 3, 3, 640), 611) * 0.01).to(DEV)
+    g, b = torch.ones(640, device=DEV), torch.zeros(640, device=DEV)
+    part = torch.zeros((1, 1, 32, 2), device=DEV)
+    try:
+        lib.sdeo_debug_force_gemm_plan(C.c_int(35), C.c_int(1))
+        assert ops.conv3x3_gn_in(x, wt, g, b, part) is None
+    finally:
+        lib.sdeo_debug_force_gemm_plan(C.c_int(-1), C.c_int(0))
