@@ -279,7 +279,7 @@ def main():
         fp8_check = {"what": "eps of one N=2 pass vs the reference modules (fp32) on the same fp8-dequantised weights (pass64_fp8.eps)",
                      "max_abs_err_over_ref_max": round(float(err.max() / ref.abs().max()), 5),
                      "mean_abs_err_over_ref_max": round(float(err.mean() / ref.abs().max()), 6),
-                     "gemm_launches_on_fp8_mfma_per_pass": int(L.load().sdeo_debug_mx_launches(rt.handle))}
+                     "gemm_launches_on_fp8_mfma_in_configured_programs": int(L.load().sdeo_debug_mx_launches(rt.handle))}      # ControlNet + UNet (+ the no-control UNet variant)
     roof = None
     if not a.no_roofline and rank == 0:
         import stablediffusioneo_amd.cldm.ddim_hacked as dh
@@ -318,7 +318,7 @@ def main():
         step_counters = sj.get("summary") if sj else None
         step_traffic = None
         if step_counters:          # HBM-side bytes of ONE DDIM step (FETCH_SIZE x 2 + WRITE_SIZE, eager single-stream counter pass)
-            step_traffic = int((step_counters.get("hbm_read_GB_per_step", 0) + step_counters.get("hbm_write_GB_per_step", 0)) * 1e9) or None
+            step_traffic = int((step_counters.get("l2_fabric_read_GB_per_step", 0) + step_counters.get("l2_fabric_write_GB_per_step", 0)) * 1e9) or None
         # The headline fraction is that of the conv / GEMM FAMILY (all implicit-GEMM, halo-conv and GEMM launches of the image: the
         # group that holds most of the device time), not of the single best (kernel, shape) pair -- the pair is kept under
         # `dominant_pair`.  achieved = sum of algorithmic FLOP of the family's launches / sum of their HIP-event durations.

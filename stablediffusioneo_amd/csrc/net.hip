@@ -578,7 +578,7 @@ struct Builder {
         p.w = reinterpret_cast<const f16*>(e->mxslab + it->second.q_off); p.ldw = it->second.cols;
         p.mx_sx = sc; p.mx_ldsx = lds;
         p.mx_sw = reinterpret_cast<const uint8_t*>(e->mxslab + it->second.s_off); p.mx_ldsw = it->second.cols / 32;
-        ++e->mx_launches;
+        if (!dry) ++e->mx_launches;
         mx_tmp.push_back(xq); mx_tmp.push_back(xs);
       }
     }

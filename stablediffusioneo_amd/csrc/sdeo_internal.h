@@ -56,7 +56,7 @@ int sdeo_debug_gemm_mx_f16(void* y, int ldy, const void* xq, const void* xs, con
 int sdeo_debug_quantize_fp8_rows(void* w_f16_inout, void* q_out, float* scale_out, int rows, int cols, void* stream);
 void sdeo_debug_next_weights_fp8(const void* q, const float* scale);
 
-/* GEMM launches of the configured programs (all of them, both build passes counted once) that run on the block-scaled fp8 MFMA
+/* GEMM launches of the configured programs (ControlNet, UNet with and without control) that run on the block-scaled fp8 MFMA
  * (sdeo_set_activation_precision(h, 8, ...)) */
 int sdeo_debug_mx_launches(sdeo_handle h);
 

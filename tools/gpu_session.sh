@@ -52,7 +52,7 @@ s_step_counters() {
 # the round-1 whole-bench --pmc crash (rocprofv3 died inside its dispatch interception under graph replay + the two-stream fork /
 # join): ONE pass each with only one of the two switched on, stderr kept; never retried
 s_pmc_mode() { mode=$1; cd /tmp; export TMPDIR=/tmp
-  if [ $mode = graph_only ]; then export SDEO_STEPCTR_GRAPH=1 SDEO_STEPCTR_OVERLAP=0; else export SDEO_STEPCTR_GRAPH=0 SDEO_STEPCTR_OVERLAP=1; fi
+  if [ $mode = graph_only ]; then export SDEO_STEPCTR_GRAPH=1 SDEO_STEPCTR_OVERLAP=0; elif [ $mode = both ]; then export SDEO_STEPCTR_GRAPH=1 SDEO_STEPCTR_OVERLAP=1; else export SDEO_STEPCTR_GRAPH=0 SDEO_STEPCTR_OVERLAP=1; fi
   timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES --kernel-include-regex sdeo -d $OUT/pmc_$mode -o p -- python3 $R/tools/step_counters.py 512 short > $OUT/pmc_$mode.out 2> $OUT/pmc_$mode.err; rc=$?
   unset SDEO_STEPCTR_GRAPH SDEO_STEPCTR_OVERLAP; cd $R; echo "pmc $mode rc=$rc"; tail -1 $OUT/pmc_$mode.out; tail -3 $OUT/pmc_$mode.err
   find $OUT/pmc_$mode -name "*.db" -size +5M -delete; [ $rc -ge 124 ] && return $rc; return 0; }
@@ -72,6 +72,8 @@ for st in "$@"; do
     step_counters) step step_counters s_step_counters ;;
     pmc_graph_only) step pmc_graph_only s_pmc_mode graph_only ;;
     pmc_overlap_only) step pmc_overlap_only s_pmc_mode overlap_only ;;
+    pmc_both) step pmc_both s_pmc_mode both ;;
+    benchx:*) a=${st#benchx:}; nm=$(echo $a | tr -d ',-' | cut -c1-30); step "$st" bash -c "timeout -k 10 500 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline $(echo $a | tr ',' ' ') > $OUT/benchx_$nm.json 2> $OUT/benchx_$nm.err; rc=\$?; head -c 900 $OUT/benchx_$nm.json; echo; exit \$rc" ;;
     py:*) a=${st#py:}; step "$st" bash -c "timeout -k 10 600 python $(echo $a | tr ',' ' ') > $OUT/py_$N.log 2>&1; rc=\$?; tail -25 $OUT/py_$N.log; exit \$rc" ;;
     *) echo "unknown step $st" ;;
   esac
