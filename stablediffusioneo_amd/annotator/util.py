@@ -69,7 +69,15 @@ def _lanczos4_axis(ssize: int, dsize: int):
 
 def _area_axis(ssize: int, dsize: int):
     """CSR table (start[dsize + 1], index, weight) of INTER_AREA: covered fractions when the axis shrinks, OpenCV's area-mode
-    linear pair when it grows"""
+    linear pair when it grows.
+
+    Known deviations from cv2 (cv2 is not installed in this image, so INTER_AREA is "parity unpinned"; the Lanczos path, the one
+    `process()` takes for the benchmark sizes, is the integer-exact one):
+      * both axes shrinking by the SAME INTEGER factor: cv2 takes `resizeAreaFast_` (integer sum of the scale x scale cell, then
+        `saturate_cast<uchar>((sum + area/2) / area)` style rounding for u8); here the cell is averaged in fp32 with weights 1/area
+        and rounded to nearest even -- results can differ by 1 code on exact .5 ties;
+      * an axis that GROWS under INTER_AREA: cv2 runs its u8 bilinear kernel in 11-bit fixed point (weights x 2048, two rounding
+        shifts); here the linear pair is applied in fp32 -- differences of at most 1 code."""
     scale = np.float64(ssize) / np.float64(dsize)
     start, idx, wgt = [0], [], []
     for d in range(dsize):
