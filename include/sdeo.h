@@ -191,6 +191,11 @@ int sdeo_configure(sdeo_handle h, int n, int latent_h, int latent_w);
 #define SDEO_HINT_CACHED 1
 #define SDEO_CONTEXT_CACHED 2
 #define SDEO_NO_CONTROL 4 /* apply_model only: the c_concat=None branch (UNet without ControlNet) */
+/* The time embedding (timestep_embedding -> time_embed MLP -> every ResBlock's emb_layers, openaimodel.py:777-781, 255-275)
+ * depends only on t.  A sampler that knows its schedule hands it over once (sdeo_set_timestep_table) and then passes
+ * SDEO_TIMESTEP_ROW(i) instead of a timesteps pointer: every image of the batch runs at timestep i of that table. */
+#define SDEO_TIMESTEP_ROW(i) (8 | ((i) << 8))
+#define SDEO_MAX_TABLE_STEPS 128
 
 /* ControlNet.forward (cldm/cldm.py:284-305).  NCHW fp32 at the boundary:
  *   x_noisy [n][4][h][w], hint [n][3][8h][8w] in [0,1], timesteps int64 [n], context [n][77][768],
@@ -211,6 +216,23 @@ int sdeo_unet_forward(sdeo_handle h, const float* x_noisy, const int64_t* timest
 int sdeo_apply_model(sdeo_handle h, const float* x_noisy, const float* hint, const int64_t* timesteps,
                      const float* context, const float* host_control_scales, int only_mid_control, int flags,
                      float* eps, void* stream);
+
+/* Time-embedding table of a sampling schedule: host_timesteps int64[count] (HOST pointer, count <= SDEO_MAX_TABLE_STEPS), e.g.
+ * np.flip(ddim_timesteps) of cldm/ddim_hacked.py:137.  Runs the embedding MLPs of both networks once for all rows; the table stays
+ * valid until the next sdeo_configure / sdeo_set_timestep_table.  Not capturable (synchronises `stream`). */
+int sdeo_set_timestep_table(sdeo_handle h, const int64_t* host_timesteps, int count, void* stream);
+
+/* One DDIM step of the classifier-free-guidance pair, eta = 0 (p_sample_ddim, cldm/ddim_hacked.py:183-231, with the two
+ * apply_model calls batched as [x; x] -- configured n = 2 x latents, conditional half first, as sdeo_apply_model sees it from the
+ * sampler): eps = apply_model([x; x]) with the hint block and context K / V cached by an earlier sdeo_apply_model call and the
+ * time embedding of row `table_row`; e = eps_u + cfg_scale (eps_c - eps_u); pred_x0 = (x - sqrt(1 - a_t) e) / sqrt(a_t);
+ * x <- sqrt(a_prev) pred_x0 + sqrt(1 - a_prev) e.  x [n/2][4][h][w] fp32 is updated IN PLACE, pred_x0 (may be NULL) receives the
+ * prediction.  Arithmetic and rounding are those of sdeo_apply_model + sdeo_cfg_ddim_step (bit-identical results); what is saved
+ * is the NCHW fp32 round trip of eps and the latent between the two.  flags: SDEO_STEP_LATENT_STAGED = x is exactly what the
+ * previous sdeo_ddim_step on this handle left (its fp16 copy is already staged; skips one conversion launch).  Capturable. */
+#define SDEO_STEP_LATENT_STAGED 16
+int sdeo_ddim_step(sdeo_handle h, float* x, float* pred_x0, int table_row, float cfg_scale, float a_t, float a_prev,
+                   float sqrt_one_minus_at, const float* host_control_scales, int only_mid_control, int flags, void* stream);
 
 /* decode_first_stage: z/scale_factor -> post_quant_conv -> Decoder (model.py:619-652).
  * z [n][4][h][w] fp32 NCHW -> images [n][3][8h][8w] fp32 NCHW in [-1,1]; images_u8 (optional, may be NULL)

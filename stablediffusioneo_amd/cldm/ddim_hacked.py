@@ -218,29 +218,29 @@ class DDIMSampler(object):
         intermediates["pred_x0"].append(pred_x0)
         key = (rt.generation, tuple(img.shape), tuple(int(t) for t in time_range), float(scale), int(log_every_t),
                tuple(float(v) for v in m.control_scales), bool(m.only_mid_control), getattr(self, "_schedule_key", None), LOOP_GRAPH_STEPS)
+        if getattr(rt, "_table_key", None) != (rt.generation, tuple(int(t) for t in time_range)):
+            rt.set_timestep_table(time_range)            # another schedule used the runtime since (the graphs read the table by address)
         if getattr(self, "_loop_key", None) != key:
             self._loop_key = None
             self._loop_x = torch.empty_like(img)
             self._loop_x.copy_(img)
             a_t, a_p, s1m = self.ddim_alphas, self.ddim_alphas_prev, self.ddim_sqrt_one_minus_alphas
-            flags = HINT_CACHED | CONTEXT_CACHED
+            # the schedule is known: the time embeddings of all steps were computed once above (row i = step i of the loop) and each step is
+            # ONE library call (sdeo_ddim_step: apply_model on [x; x] + CFG + DDIM update, x updated in place in the fixed buffer)
+            self._loop_pred = torch.empty_like(img)
             torch.cuda.synchronize(dev)
-            graphs, kept_x, kept_p, last_pred = [], [], [], None
+            graphs, kept_x, kept_p = [], [], []
             per_graph = LOOP_GRAPH_STEPS if LOOP_GRAPH_STEPS > 0 else total_steps
             for first in range(1, total_steps, per_graph):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    x = self._loop_x
                     for i in range(first, min(first + per_graph, total_steps)):
                         index = total_steps - i - 1
-                        t2 = torch.full((2 * b,), int(time_range[i]), device=dev, dtype=torch.long)
-                        eps2 = rt.apply_model(torch.cat([x, x]), None, t2, None, m.control_scales, m.only_mid_control, flags)
-                        x, last_pred = ops.cfg_ddim_step(x, eps2[:b], eps2[b:], scale, float(a_t[index]), float(a_p[index]), 0.0,
-                                                         float(s1m[index]), noise=None)
+                        rt.ddim_step(self._loop_x, self._loop_pred, i, scale, float(a_t[index]), float(a_p[index]), float(s1m[index]),
+                                     m.control_scales, m.only_mid_control, staged=i > first)
                         if index % log_every_t == 0:
-                            kept_x.append(x)
-                            kept_p.append(last_pred)
-                    self._loop_x.copy_(x)              # the next graph (and the caller) read the latent from the fixed buffer
+                            kept_x.append(self._loop_x.clone())
+                            kept_p.append(self._loop_pred.clone())
                 graphs.append(g)
             self._loop_graphs, self._loop_kept = graphs, (kept_x, kept_p)
             self._loop_key = key

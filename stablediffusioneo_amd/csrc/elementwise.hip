@@ -272,20 +272,84 @@ int geglu_interleave_f32(float* y, const float* x, int H, hipStream_t stream) {
 // CFG combine + DDIM update (`cldm/ddim_hacked.py:192,208-231`), eps-parameterisation, fp32 NCHW latents.
 //   e = eps_u + s*(eps_c - eps_u);  pred_x0 = (x - sqrt(1-a_t) e)/sqrt(a_t)
 //   x_prev = sqrt(a_prev) pred_x0 + sqrt(1 - a_prev - sigma^2) e + sigma * noise
+// one element of the update; shared by both kernels below so that they round alike
+__device__ __forceinline__ void cfg_ddim_elem(float x, float c, float u, bool guided, float s, float rsqrt_at, float sqrt_aprev, float dir_coef,
+                                              float sqrt_1m_at, float& p0, float& xp) {
+  // explicit fused multiply-adds: left to the compiler, the contraction of a * b + c * d differs from kernel to kernel
+  const float e = guided ? fmaf(s, c - u, u) : c;
+  p0 = fmaf(-sqrt_1m_at, e, x) * rsqrt_at;
+  xp = fmaf(sqrt_aprev, p0, dir_coef * e);
+}
+
 __global__ __launch_bounds__(256) void cfg_ddim_kernel(float* __restrict__ x_prev, float* __restrict__ pred_x0,
                                                        const float* __restrict__ x, const float* __restrict__ ec,
                                                        const float* __restrict__ eu, const float* __restrict__ noise,
                                                        float s, float rsqrt_at, float sqrt_aprev, float dir_coef, float sigma,
                                                        float sqrt_1m_at, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float c = ec[i];
-    const float e = eu ? eu[i] + s * (c - eu[i]) : c;
-    const float p0 = (x[i] - sqrt_1m_at * e) * rsqrt_at;
-    float xp = sqrt_aprev * p0 + dir_coef * e;
+    float p0, xp;
+    cfg_ddim_elem(x[i], ec[i], eu ? eu[i] : 0.f, eu != nullptr, s, rsqrt_at, sqrt_aprev, dir_coef, sqrt_1m_at, p0, xp);
     if (noise) xp += sigma * noise[i];
     x_prev[i] = xp;
     if (pred_x0) pred_x0[i] = p0;
   }
+}
+
+// The same update for the fused CFG pair inside the library (sdeo_ddim_step): eps comes straight from the UNet's fp16 NHWC output
+// (images 0..b-1 conditional, b..2b-1 unconditional), x [b][C][HW] fp32 is updated in place, and the fp16 NHWC latent of the NEXT
+// forward (both halves of the pair, padding channels zero) is written on the way out.  One thread per (image, pixel).
+__global__ __launch_bounds__(256) void cfg_ddim_pair_kernel(float* __restrict__ x, float* __restrict__ pred_x0, const f16* __restrict__ eps,
+                                                            int lde, f16* __restrict__ x0, int ld0, int b, int C, int HW, float s,
+                                                            float rsqrt_at, float sqrt_aprev, float dir_coef, float sqrt_1m_at) {
+  const int64_t total = (int64_t)b * HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / HW, pix = i - n * HW;
+    const f16* ec = eps + i * lde;
+    const f16* eu = eps + (i + total) * lde;
+    for (int c = 0; c < ld0; ++c) {
+      f16 v = (f16)0.f;
+      if (c < C) {
+        const int64_t j = (n * C + c) * HW + pix;
+        float p0, xp;
+        cfg_ddim_elem(x[j], (float)ec[c], (float)eu[c], true, s, rsqrt_at, sqrt_aprev, dir_coef, sqrt_1m_at, p0, xp);
+        x[j] = xp;
+        if (pred_x0) pred_x0[j] = p0;
+        v = (f16)xp;
+      }
+      x0[i * ld0 + c] = v;
+      x0[(i + total) * ld0 + c] = v;
+    }
+  }
+}
+
+int cfg_ddim_pair(float* x, float* pred_x0, const f16* eps, int lde, f16* x0, int ld0, int b, int C, int HW, float cfg_scale, float a_t,
+                  float a_prev, float sqrt_one_minus_at, hipStream_t stream) {
+  SDEO_CHECK(x && eps && x0 && b > 0 && C > 0 && HW > 0 && lde >= C && ld0 >= C, "cfg_ddim_pair: bad operand");
+  SDEO_CHECK(a_t > 0.f && (1.f - a_prev) >= 0.f, "cfg_ddim_pair: invalid schedule a_t=%g a_prev=%g", a_t, a_prev);
+  hipLaunchKernelGGL(cfg_ddim_pair_kernel, grid_for((int64_t)b * HW), dim3(256), 0, stream, x, pred_x0, eps, lde, x0, ld0, b, C, HW,
+                     cfg_scale, 1.0f / sqrtf(a_t), sqrtf(a_prev), sqrtf(1.f - a_prev), sqrt_one_minus_at);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+// latent [b][C][HW] fp32 -> fp16 NHWC for BOTH halves of the CFG pair (images n and n + b), padding channels zero
+__global__ __launch_bounds__(256) void latent_pair_kernel(f16* __restrict__ x0, int ld0, const float* __restrict__ x, int b, int C, int HW) {
+  const int64_t total = (int64_t)b * HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n = i / HW, pix = i - n * HW;
+    for (int c = 0; c < ld0; ++c) {
+      const f16 v = c < C ? (f16)x[(n * C + c) * HW + pix] : (f16)0.f;
+      x0[i * ld0 + c] = v;
+      x0[(i + total) * ld0 + c] = v;
+    }
+  }
+}
+
+int latent_pair_to_nhwc(f16* x0, int ld0, const float* x, int b, int C, int HW, hipStream_t stream) {
+  SDEO_CHECK(x0 && x && b > 0 && C > 0 && HW > 0 && ld0 >= C, "latent_pair_to_nhwc: bad operand");
+  hipLaunchKernelGGL(latent_pair_kernel, grid_for((int64_t)b * HW), dim3(256), 0, stream, x0, ld0, x, b, C, HW);
+  SDEO_HIP(hipGetLastError());
+  return 0;
 }
 
 int cfg_ddim_step(float* x_prev, float* pred_x0, const float* x, const float* eps_c, const float* eps_u, const float* noise,

@@ -188,6 +188,9 @@ int resize_lanczos4_u8(uint8_t* dst, const uint8_t* src, int h, int w, int c, in
 int resize_area_u8(uint8_t* dst, const uint8_t* src, int h, int w, int c, int dh, int dw, const int* xstart, const int* xidx,
                    const float* xw, const int* ystart, const int* yidx, const float* yw, hipStream_t stream);
 // classifier-free guidance + DDIM update on NCHW fp32 latents (ddim_hacked.py:192,208-231)
+int cfg_ddim_pair(float* x, float* pred_x0, const f16* eps, int lde, f16* x0, int ld0, int b, int C, int HW, float cfg_scale, float a_t,
+                  float a_prev, float sqrt_one_minus_at, hipStream_t stream);
+int latent_pair_to_nhwc(f16* x0, int ld0, const float* x, int b, int C, int HW, hipStream_t stream);
 int cfg_ddim_step(float* x_prev, float* pred_x0, const float* x, const float* eps_c, const float* eps_u, const float* noise,
                   float cfg_scale, float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at, int64_t n,
                   hipStream_t stream);

@@ -267,8 +267,21 @@ struct sdeo_handle_s {
   float scales[13];
   int only_mid = 0;
   bool use_control = true;
+  // time embedding (`openaimodel.py:777-781` + every ResBlock's emb_layers): fp32 [N][emb_total] per net, written by p_temb[net] from
+  // in_t -- or, for a sampler that announced its schedule (sdeo_set_timestep_table), one row of a table computed once per schedule.
+  // The ResBlock convs read their pointer / row stride at LAUNCH time (emb_cur / emb_ld_cur), like the control scales.
+  static constexpr int kTabRows = 128;
+  float* emb_all[2] = {nullptr, nullptr};
+  float* temb_tab[2] = {nullptr, nullptr};     // [kTabRows][emb_total[net]]
+  int64_t* tab_t = nullptr;                    // device int64 [kTabRows]
+  int tab_count = 0;
+  const float* emb_cur[2] = {nullptr, nullptr};
+  int emb_ld_cur[2] = {0, 0};
+  T x0;                  // fp16 NHWC copy of the latent input, shared by ControlNet and UNet (p_x0 writes it from in_x)
+  T eps16;               // the UNet's eps before the NCHW fp32 export (p_eps_export), read directly by sdeo_ddim_step
   // programs
   Program p_hint, p_ctx_cn, p_ctx_unet, p_cn, p_cn_export, p_ctrl_import, p_unet_enc, p_unet_dec, p_unet_noctrl, p_vae;
+  Program p_temb[2], p_temb_tab, p_x0, p_eps_export;
   std::vector<size_t> ctrl_elems;
   size_t device_bytes = 0;
   // profiling (sdeo_profile_*): HIP events around every launch of the next programs
@@ -493,6 +506,7 @@ struct RowStats {                     // per-row (sum, sumsq) partials of a [row
 
 struct ConvOpts {                     // conv / gemm options
   const float* bias2 = nullptr; int ld_bias2 = 0;
+  const float* const* bias2_cur = nullptr; const int* ld_bias2_cur = nullptr; int bias2_off = 0;    // read at launch time (time embedding)
   const T* res = nullptr;
   int act = 0;
   const float* scale_host = nullptr;   // read at launch time (control scales)
@@ -561,7 +575,7 @@ struct Builder {
   const float* named_v(const std::string& name) { return reinterpret_cast<const float*>(e->wslab + e->named_off.at(name)); }
 
 
-  void launch_conv(ConvGemm p, const float* scale_host, RowStats* stats = nullptr, T* gn_y = nullptr) {
+  void launch_conv(ConvGemm p, const float* scale_host, RowStats* stats = nullptr, T* gn_y = nullptr, const ConvOpts* lo = nullptr) {
     if (e->act_bits == 8 && e->mxslab && p.M >= e->mx_min_rows && p.R == 1 && p.S == 1 && p.stride == 1 && !p.ups && p.K % 128 == 0 &&
         p.K == p.Cin && p.ldx % 16 == 0 && !p.bias_per_row && p.y && !p.y32) {
       // block-scaled fp8 on both sides: pack the activations (one launch), run the GEMM on the fp8 MFMA
@@ -622,10 +636,14 @@ struct Builder {
     }
     Engine* eng = e;
     const int sel = ws_sel;
-    push([p, scale_host, eng, sel](hipStream_t s) mutable {
+    const float* const* b2cur = lo ? lo->bias2_cur : nullptr;
+    const int* b2ld = lo ? lo->ld_bias2_cur : nullptr;
+    const int b2off = lo ? lo->bias2_off : 0;
+    push([p, scale_host, eng, sel, b2cur, b2ld, b2off](hipStream_t s) mutable {
       p.workspace = sel ? eng->splitk_ws2 : eng->splitk_ws;
       p.workspace_bytes = eng->splitk_ws_bytes;
       if (scale_host) p.scale = *scale_host;
+      if (b2cur) { p.bias2 = *b2cur + b2off; p.ld_bias2 = *b2ld; }
       return conv_gemm(p, s);
     }, conv_gemm_kernel_name(p), 2.0 * p.M * p.N * p.K,
        2.0 * ((double)p.M * p.Cin * (p.R * p.S > 1 ? 1 : 1) + (double)p.N * p.K + (double)p.M * p.N),
@@ -683,7 +701,7 @@ struct Builder {
     }
     const bool want_gn = o.gn_next && !o.out && !o.scale_host && cs == y.c;
     if (want_gn) reserve_gn_partials(p, y);
-    launch_conv(p, o.scale_host, o.stats, want_gn ? &y : nullptr);
+    launch_conv(p, o.scale_host, o.stats, want_gn ? &y : nullptr, &o);
     T r = y;
     if (o.out) r.off = (size_t)-1;
     return r;
@@ -802,11 +820,14 @@ struct Builder {
 };
 
 // ResBlock._forward (`openaimodel.py:255-275`)
-static T build_res(Builder& b, const std::string& ns, const Blk& blk, const T& x, const float* emb_all, int emb_ld, const T* out = nullptr) {
+static T build_res(Builder& b, const std::string& ns, const Blk& blk, const T& x, int net, const T* out = nullptr) {
   const std::string p = ns + blk.name;
   Builder::CO o1;
-  o1.bias2 = emb_all + b.e->emb_row.at(p);
-  o1.ld_bias2 = emb_ld;
+  o1.bias2_off = b.e->emb_row.at(p);
+  o1.bias2 = b.e->emb_all[net] + o1.bias2_off;     // what planning / autotune see; the launch reads emb_cur / emb_ld_cur
+  o1.ld_bias2 = b.e->emb_total[net];
+  o1.bias2_cur = &b.e->emb_cur[net];
+  o1.ld_bias2_cur = &b.e->emb_ld_cur[net];
   o1.gn_next = true;
   T h1 = b.gn_conv(x, p + ".in_layers.0", 1e-5f, 1, p + ".in_layers.2", blk.cout, o1);
   T skip;
@@ -878,14 +899,14 @@ static T build_attn(Builder& b, const std::string& ns, const Blk& blk, const T& 
   return y;
 }
 
-// time_embed MLP + stacked emb_layers projection: returns fp32 [N][emb_total] (persistent buffer)
-static float* build_time_embed(Builder& b, const std::string& ns, int net, int N) {
+// time_embed MLP + stacked emb_layers projection: int64 t[rows] -> fp32 out[rows][emb_total[net]]
+static void build_time_embed(Builder& b, const std::string& ns, int net, int rows, const int64_t* tp, float* out) {
   const sdeo_config& c = b.e->cfg;
   const int mc = c.model_channels, emb = 4 * mc, total = b.e->emb_total[net];
-  T te = b.alloc2d(N, mc);
+  T te = b.alloc2d(rows, mc);
   {
-    f16* o = te.p; const int64_t* tp = b.e->in_t;
-    b.push([=](hipStream_t s) { return timestep_embedding(o, tp, N, mc, s); });
+    f16* o = te.p;
+    b.push([=](hipStream_t s) { return timestep_embedding(o, tp, rows, mc, s); });
   }
   Builder::CO a; a.act = 1;
   T e1 = b.gemm(te, b.wptr(ns + "time_embed.0.weight"), mc, emb, b.vptr(ns + "time_embed.0.bias"), a);
@@ -893,11 +914,8 @@ static float* build_time_embed(Builder& b, const std::string& ns, int net, int N
   // every consumer of emb applies SiLU first (emb_layers = SiLU -> Linear), so store SiLU(emb)
   T e2 = b.gemm(e1, b.wptr(ns + "time_embed.2.weight"), emb, emb, b.vptr(ns + "time_embed.2.bias"), a);
   b.release(e1);
-  T all32 = b.alloc2d(N, total * 2);   // fp32 [N][total] stored in an fp16-typed arena block
-  float* out = reinterpret_cast<float*>(all32.p);
   b.gemm(e2, b.named_w(ns + "emb_all.weight"), emb, total, b.named_v(ns + "emb_all.bias"), Builder::CO(), out, total);
   b.release(e2);
-  return out;   // all32 intentionally never released inside this program
 }
 
 static std::vector<const Blk*> attn_blocks(const UPlan& p) {
@@ -961,6 +979,8 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
   }
   bt.ctx16 = b.alloc2d(N * TkS, c.context_dim);
   bt.hint_feat = b.alloc(N, h, w, c.model_channels);
+  e->x0 = b.alloc(N, h, w, round8(c.in_channels));
+  e->eps16 = b.alloc(N, h, w, 4 * ((c.out_channels + 3) / 4));
   const char* nss[2] = {NS_UNET, NS_CN};
   const UPlan* plans[2] = {&e->uplan, &e->cplan};
   for (int net = 0; net < 2; ++net)
@@ -969,6 +989,28 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
       kv.kv = b.alloc2d(N * TkS, 2 * ab->cin);
       bt.kv[net][std::string(nss[net]) + ab->name] = kv;
     }
+
+  // ---- small programs (their temporaries come and go: only after every persistent tensor has its place)
+  {   // latent in: NCHW fp32 -> NHWC fp16, once for both networks
+    b.prog = &e->p_x0;
+    f16* o = e->x0.p; const float* in = e->in_x; const int Cc = c.in_channels, ld = e->x0.ld, HW = h * w;
+    b.push([=](hipStream_t s) { return nchw_f32_to_nhwc_f16(o, ld, in, N, Cc, HW, 1.0f, s); });
+    b.prog = &e->p_eps_export;
+    float* eo = e->out_eps; const f16* ein = e->eps16.p; const int eld = e->eps16.ld, Ce = c.out_channels;
+    b.push([=](hipStream_t s) { return nhwc_f16_to_nchw_f32(eo, ein, eld, N, Ce, HW, 1.0f, s); });
+  }
+  {   // time embedding: per forward (rows = N, t from in_t) and per schedule (rows = kTabRows, t from tab_t), both networks
+    // (the ControlNet's runs on the side stream beside the UNet encoder: its temporaries and split-K workspace are the side stream's)
+    const char* tns[2] = {NS_UNET, NS_CN};
+    for (int net = 0; net < 2; ++net) {
+      b.prog = &e->p_temb[net];
+      if (net == 1) { b.arena = &arena2; b.base = e->arena2; b.ws_sel = 1; }
+      build_time_embed(b, tns[net], net, N, e->in_t, e->emb_all[net]);
+      if (net == 1) { b.arena = &arena; b.base = e->arena; b.ws_sel = 0; }
+    }
+    b.prog = &e->p_temb_tab;
+    for (int net = 0; net < 2; ++net) build_time_embed(b, tns[net], net, Engine::kTabRows, e->tab_t, e->temb_tab[net]);
+  }
 
   // ---- context programs: fp32 [N][77][768] -> fp16 padded; K | V = ctx [Wk; Wv]^T per attn block, one GEMM each
   for (int net = 0; net < 2; ++net) {
@@ -1005,15 +1047,14 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
     }
   }
 
-  auto run_blocks = [&](const std::string& ns, const std::vector<Blk>& blocks, T x, bool release_in, const float* emb_all, int emb_ld,
-                        int net, const T* final_out) -> T {
+  auto run_blocks = [&](const std::string& ns, const std::vector<Blk>& blocks, T x, bool release_in, int net, const T* final_out) -> T {
     for (size_t i = 0; i < blocks.size(); ++i) {
       const Blk& blk = blocks[i];
       const T* out = (i + 1 == blocks.size()) ? final_out : nullptr;
       T y;
       switch (blk.kind) {
         case B_CONV_IN: { Builder::CO o; o.out = out; o.gn_next = true; y = b.conv(x, ns + blk.name, blk.cout, 3, 1, 0, o); break; }
-        case B_RES: y = build_res(b, ns, blk, x, emb_all, emb_ld, out); break;
+        case B_RES: y = build_res(b, ns, blk, x, net, out); break;
         case B_ATTN: y = build_attn(b, ns, blk, x, bt.kv[net].at(ns + blk.name), out); break;
         case B_DOWN: { Builder::CO o; o.out = out; o.gn_next = true; y = b.conv(x, ns + blk.name + ".op", blk.cout, 3, 2, 0, o); break; }
         case B_UP: { Builder::CO o; o.out = out; o.gn_next = true; y = b.conv(x, ns + blk.name + ".conv", blk.cout, 3, 1, 1, o); break; }
@@ -1029,28 +1070,21 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
     b.prog = &e->p_cn;
     b.arena = &arena2; b.base = e->arena2; b.ws_sel = 1;
     const std::string ns = NS_CN;
-    float* emb_all = build_time_embed(b, ns, 1, N);
-    T x0 = b.alloc(N, h, w, round8(c.in_channels));
-    {
-      f16* o = x0.p; const float* in = e->in_x; const int Cc = c.in_channels, ld = x0.ld, HW = h * w;
-      b.push([=](hipStream_t s) { return nchw_f32_to_nhwc_f16(o, ld, in, N, Cc, HW, 1.0f, s); });
-    }
-    T hcur = x0;
+    T hcur = e->x0;
     for (size_t i = 0; i < e->cplan.in.size(); ++i) {
       T y;
       if (i == 0) {
         // input_blocks.0 conv, then h += guided_hint (residual epilogue)
         Builder::CO o; o.res = &bt.hint_feat; o.gn_next = true;
         y = b.conv(hcur, ns + e->cplan.in[0][0].name, c.model_channels, 3, 1, 0, o);
-        b.release(hcur);
       } else {
-        y = run_blocks(ns, e->cplan.in[i], hcur, true, emb_all, e->emb_total[1], 1, nullptr);
+        y = run_blocks(ns, e->cplan.in[i], hcur, true, 1, nullptr);
       }
       hcur = y;
       Builder::CO zo; zo.out = &e->ctrl[i];
       b.conv(hcur, ns + "zero_convs." + std::to_string(i) + ".0", e->cplan.in_ch[i], 1, 1, 0, zo);
     }
-    T m = run_blocks(ns, e->cplan.mid, hcur, true, emb_all, e->emb_total[1], 1, nullptr);
+    T m = run_blocks(ns, e->cplan.mid, hcur, true, 1, nullptr);
     Builder::CO zo; zo.out = &e->ctrl[e->cplan.in.size()];
     b.conv(m, ns + "middle_block_out.0", e->cplan.in_ch.back(), 1, 1, 0, zo);
     b.release(m);
@@ -1078,16 +1112,10 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
     const bool with_ctrl = variant == 0;
     b.prog = with_ctrl ? &e->p_unet_enc : &e->p_unet_noctrl;
     const std::string ns = NS_UNET;
-    float* emb_all = build_time_embed(b, ns, 0, N);
-    T x0 = b.alloc(N, h, w, round8(c.in_channels));
-    {
-      f16* o = x0.p; const float* in = e->in_x; const int Cc = c.in_channels, ld = x0.ld, HW = h * w;
-      b.push([=](hipStream_t s) { return nchw_f32_to_nhwc_f16(o, ld, in, N, Cc, HW, 1.0f, s); });
-    }
     std::vector<T> hs;
-    T hcur = x0;
+    T hcur = e->x0;
     for (size_t i = 0; i < e->uplan.in.size(); ++i) {
-      T y = run_blocks(ns, e->uplan.in[i], hcur, i == 0, emb_all, e->emb_total[0], 0, nullptr);
+      T y = run_blocks(ns, e->uplan.in[i], hcur, false, 0, nullptr);
       hs.push_back(y);
       hcur = y;
     }
@@ -1098,7 +1126,7 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
     T skip = hs.back();
     T cat = cat_for(e->uplan.mid.back().cout, skip);
     T view = cat; view.c = e->uplan.mid.back().cout; view.off = (size_t)-1;
-    T m = run_blocks(ns, e->uplan.mid, hcur, false, emb_all, e->emb_total[0], 0, &view);
+    T m = run_blocks(ns, e->uplan.mid, hcur, false, 0, &view);
     (void)m;
     if (with_ctrl) b.prog = &e->p_unet_dec;     // everything below needs the controls: runs after the join
     if (with_ctrl) {   // h += control.pop()
@@ -1128,18 +1156,14 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
         const int up = blocks.back().kind == B_UP ? 2 : 1;
         T ncat = b.alloc(cat.n, cat.h * up, cat.w * up, c_h + nskip.c);
         T nview = ncat; nview.c = c_h; nview.off = (size_t)-1;
-        run_blocks(ns, blocks, cat, true, emb_all, e->emb_total[0], 0, &nview);
+        run_blocks(ns, blocks, cat, true, 0, &nview);
         cat = ncat;
       } else {
-        T y = run_blocks(ns, blocks, cat, true, emb_all, e->emb_total[0], 0, nullptr);
+        T y = run_blocks(ns, blocks, cat, true, 0, nullptr);
         Builder::CO oo; oo.cout_store = 4 * ((c.out_channels + 3) / 4);
-        T eps = b.gn_conv(y, ns + "out.0", 1e-5f, 1, ns + "out.2", c.out_channels, oo);
+        oo.out = &e->eps16;
+        b.gn_conv(y, ns + "out.0", 1e-5f, 1, ns + "out.2", c.out_channels, oo);
         b.release(y);
-        {
-          float* o = e->out_eps; const f16* in = eps.p; const int ld = eps.ld, Cc = c.out_channels, HW = h * w;
-          b.push([=](hipStream_t s) { return nhwc_f16_to_nchw_f32(o, in, ld, N, Cc, HW, 1.0f, s); });
-        }
-        b.release(eps);
       }
     }
   }
@@ -1270,8 +1294,9 @@ static void free_configured(Engine* e) {
   if (e->arena2) (void)hipFree(e->arena2);
   e->arena2 = nullptr;
   for (Program* p : {&e->p_hint, &e->p_ctx_cn, &e->p_ctx_unet, &e->p_cn, &e->p_cn_export, &e->p_ctrl_import, &e->p_unet_enc,
-                     &e->p_unet_dec, &e->p_unet_noctrl, &e->p_vae})
+                     &e->p_unet_dec, &e->p_unet_noctrl, &e->p_vae, &e->p_temb[0], &e->p_temb[1], &e->p_temb_tab, &e->p_x0, &e->p_eps_export})
     p->clear();
+  e->tab_count = 0;
 }
 
 }  // namespace
@@ -1484,6 +1509,12 @@ int sdeo_configure(sdeo_handle h, int n, int latent_h, int latent_w) {
   if (int rc = dev_alloc(h, &h->in_hint, (size_t)n * c.hint_channels * px * 64 * 4)) return rc;
   if (int rc = dev_alloc(h, &h->in_ctx, (size_t)n * c.context_len * c.context_dim * 4)) return rc;
   if (int rc = dev_alloc(h, &h->in_t, (size_t)n * 8)) return rc;
+  if (int rc = dev_alloc(h, &h->tab_t, (size_t)sdeo_handle_s::kTabRows * 8)) return rc;
+  SDEO_HIP(hipMemset(h->tab_t, 0, (size_t)sdeo_handle_s::kTabRows * 8));
+  for (int net = 0; net < 2; ++net) {
+    if (int rc = dev_alloc(h, &h->emb_all[net], (size_t)n * h->emb_total[net] * 4)) return rc;
+    if (int rc = dev_alloc(h, &h->temb_tab[net], (size_t)sdeo_handle_s::kTabRows * h->emb_total[net] * 4)) return rc;
+  }
   if (int rc = dev_alloc(h, &h->out_eps, (size_t)n * c.out_channels * px * 4)) return rc;
   if (int rc = dev_alloc(h, &h->vae_in, (size_t)c.vae_z_channels * px * 4)) return rc;
   if (int rc = dev_alloc(h, &h->vae_out, (size_t)c.vae_out_ch * px * 64 * 4)) return rc;
@@ -1557,15 +1588,59 @@ static int stage_inputs(sdeo_handle h, const float* x, const float* hint, const 
   SDEO_CHECK(h->finalized, "weights not finalized (call sdeo_finalize_weights)");            \
   SDEO_CHECK(h->arena, "not configured (call sdeo_configure)")
 
+// time embedding of this forward: row `row` of the schedule table (>= 0; every image of the batch at that timestep), or in_t via p_temb
+static int select_time(sdeo_handle h, int flags, const int64_t* timesteps, const char* who, int* row_out) {
+  const int row = (flags & 8) ? (flags >> 8) : -1;
+  SDEO_CHECK(row >= 0 || timesteps, "%s: timesteps required", who);
+  SDEO_CHECK(row < h->tab_count, "%s: timestep row %d, but the table holds %d (sdeo_set_timestep_table)", who, row, h->tab_count);
+  for (int net = 0; net < 2; ++net) {
+    h->emb_cur[net] = row >= 0 ? h->temb_tab[net] + (size_t)row * h->emb_total[net] : h->emb_all[net];
+    h->emb_ld_cur[net] = row >= 0 ? 0 : h->emb_total[net];
+  }
+  *row_out = row;
+  return 0;
+}
+
+// ControlNet || UNet encoder, join, UNet decoder: eps16 holds the result.  The latent is already in x0.
+static int run_step_programs(sdeo_handle h, bool no_control, bool time_from_table, hipStream_t s) {
+  if (no_control) {
+    if (!time_from_table) if (int rc = run(h, h->p_temb[0], s)) return rc;
+    return run(h, h->p_unet_noctrl, s);
+  }
+  if (h->overlap && !h->profiling) {
+    // fork: ControlNet on the side stream, UNet encoder + middle block on the caller's stream (capturable)
+    SDEO_HIP(hipEventRecord(h->ev_fork, s));
+    SDEO_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    if (!time_from_table) if (int rc = run(h, h->p_temb[1], h->side)) return rc;
+    if (int rc = run(h, h->p_cn, h->side)) return rc;
+    SDEO_HIP(hipEventRecord(h->ev_join, h->side));
+    if (!time_from_table) if (int rc = run(h, h->p_temb[0], s)) return rc;
+    if (int rc = run(h, h->p_unet_enc, s)) return rc;
+    SDEO_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+  } else {
+    if (!time_from_table) {
+      if (int rc = run(h, h->p_temb[1], s)) return rc;
+      if (int rc = run(h, h->p_temb[0], s)) return rc;
+    }
+    if (int rc = run(h, h->p_cn, s)) return rc;
+    if (int rc = run(h, h->p_unet_enc, s)) return rc;
+  }
+  return run(h, h->p_unet_dec, s);
+}
+
 int sdeo_controlnet_forward(sdeo_handle h, const float* x_noisy, const float* hint, const int64_t* timesteps,
                             const float* context, float* const* controls, int flags, void* stream) {
   REQUIRE_READY(h);
-  SDEO_CHECK(x_noisy && timesteps && controls, "sdeo_controlnet_forward: null argument");
+  SDEO_CHECK(x_noisy && controls, "sdeo_controlnet_forward: null argument");
   hipStream_t s = S(stream);
   const int hint_new = !(flags & 1), ctx_new = !(flags & 2);
   SDEO_CHECK(!hint_new || hint, "sdeo_controlnet_forward: hint required");
   SDEO_CHECK(!ctx_new || context, "sdeo_controlnet_forward: context required");
-  if (int rc = stage_inputs(h, x_noisy, hint, timesteps, ctx_new ? context : nullptr, hint_new, 2, s)) return rc;
+  int trow = -1;
+  if (int rc = select_time(h, flags, timesteps, "sdeo_controlnet_forward", &trow)) return rc;
+  if (int rc = stage_inputs(h, x_noisy, hint, trow < 0 ? timesteps : nullptr, ctx_new ? context : nullptr, hint_new, 2, s)) return rc;
+  if (int rc = run(h, h->p_x0, s)) return rc;
+  if (trow < 0) if (int rc = run(h, h->p_temb[1], s)) return rc;
   if (int rc = run(h, h->p_cn, s)) return rc;
   if (int rc = run(h, h->p_cn_export, s)) return rc;
   for (size_t i = 0; i < h->ctrl_elems.size(); ++i)
@@ -1577,13 +1652,17 @@ int sdeo_unet_forward(sdeo_handle h, const float* x_noisy, const int64_t* timest
                       const float* const* controls, const float* host_control_scales, int only_mid_control, float* eps,
                       int flags, void* stream) {
   REQUIRE_READY(h);
-  SDEO_CHECK(x_noisy && timesteps && eps, "sdeo_unet_forward: null argument");
+  SDEO_CHECK(x_noisy && eps, "sdeo_unet_forward: null argument");
   hipStream_t s = S(stream);
   const int ctx_new = !(flags & 2);
   SDEO_CHECK(!ctx_new || context, "sdeo_unet_forward: context required");
-  if (int rc = stage_inputs(h, x_noisy, nullptr, timesteps, ctx_new ? context : nullptr, 0, 1, s)) return rc;
+  int trow = -1;
+  if (int rc = select_time(h, flags, timesteps, "sdeo_unet_forward", &trow)) return rc;
+  if (int rc = stage_inputs(h, x_noisy, nullptr, trow < 0 ? timesteps : nullptr, ctx_new ? context : nullptr, 0, 1, s)) return rc;
   h->only_mid = only_mid_control;
   for (int i = 0; i < 13; ++i) h->scales[i] = host_control_scales ? host_control_scales[i] : 1.0f;
+  if (int rc = run(h, h->p_x0, s)) return rc;
+  if (trow < 0) if (int rc = run(h, h->p_temb[0], s)) return rc;
   if (controls) {
     for (size_t i = 0; i < h->ctrl_elems.size(); ++i) {
       SDEO_CHECK(controls[i], "sdeo_unet_forward: control %zu is null", i);
@@ -1595,40 +1674,66 @@ int sdeo_unet_forward(sdeo_handle h, const float* x_noisy, const int64_t* timest
   } else {
     if (int rc = run(h, h->p_unet_noctrl, s)) return rc;
   }
+  if (int rc = run(h, h->p_eps_export, s)) return rc;
   return copy_in(eps, h->out_eps, (size_t)h->N * h->cfg.out_channels * h->lh * h->lw * 4, s);
 }
 
 int sdeo_apply_model(sdeo_handle h, const float* x_noisy, const float* hint, const int64_t* timesteps, const float* context,
                      const float* host_control_scales, int only_mid_control, int flags, float* eps, void* stream) {
   REQUIRE_READY(h);
-  SDEO_CHECK(x_noisy && timesteps && eps, "sdeo_apply_model: null argument");
+  SDEO_CHECK(x_noisy && eps, "sdeo_apply_model: null argument");
   hipStream_t s = S(stream);
   const int hint_new = !(flags & 1), ctx_new = !(flags & 2), no_control = (flags & 4) != 0;
   SDEO_CHECK(!ctx_new || context, "sdeo_apply_model: context required");
   SDEO_CHECK(no_control || !hint_new || hint, "sdeo_apply_model: hint required");
-  if (int rc = stage_inputs(h, x_noisy, no_control ? nullptr : hint, timesteps, ctx_new ? context : nullptr, hint_new,
+  int trow = -1;
+  if (int rc = select_time(h, flags, timesteps, "sdeo_apply_model", &trow)) return rc;
+  if (int rc = stage_inputs(h, x_noisy, no_control ? nullptr : hint, trow < 0 ? timesteps : nullptr, ctx_new ? context : nullptr, hint_new,
                             no_control ? 1 : 3, s))
     return rc;
   h->only_mid = only_mid_control;
   for (int i = 0; i < 13; ++i) h->scales[i] = host_control_scales ? host_control_scales[i] : 1.0f;
-  if (no_control) {
-    if (int rc = run(h, h->p_unet_noctrl, s)) return rc;
-  } else {
-    if (h->overlap && !h->profiling) {
-      // fork: ControlNet on the side stream, UNet encoder + middle block on the caller's stream (capturable)
-      SDEO_HIP(hipEventRecord(h->ev_fork, s));
-      SDEO_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-      if (int rc = run(h, h->p_cn, h->side)) return rc;
-      SDEO_HIP(hipEventRecord(h->ev_join, h->side));
-      if (int rc = run(h, h->p_unet_enc, s)) return rc;
-      SDEO_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
-    } else {
-      if (int rc = run(h, h->p_cn, s)) return rc;
-      if (int rc = run(h, h->p_unet_enc, s)) return rc;
-    }
-    if (int rc = run(h, h->p_unet_dec, s)) return rc;
-  }
+  if (int rc = run(h, h->p_x0, s)) return rc;
+  if (int rc = run_step_programs(h, no_control, trow >= 0, s)) return rc;
+  if (int rc = run(h, h->p_eps_export, s)) return rc;
   return copy_in(eps, h->out_eps, (size_t)h->N * h->cfg.out_channels * h->lh * h->lw * 4, s);
+}
+
+int sdeo_set_timestep_table(sdeo_handle h, const int64_t* host_timesteps, int count, void* stream) {
+  REQUIRE_READY(h);
+  SDEO_CHECK(host_timesteps && count >= 1 && count <= sdeo_handle_s::kTabRows, "sdeo_set_timestep_table: 1..%d timesteps (got %d)",
+             sdeo_handle_s::kTabRows, count);
+  hipStream_t s = S(stream);
+  int64_t padded[sdeo_handle_s::kTabRows] = {0};
+  for (int i = 0; i < count; ++i) padded[i] = host_timesteps[i];
+  h->tab_count = 0;
+  SDEO_HIP(hipMemcpyAsync(h->tab_t, padded, sizeof(padded), hipMemcpyHostToDevice, s));
+  SDEO_HIP(hipStreamSynchronize(s));          // `padded` is a stack array; this call is made once per schedule, outside any capture
+  if (int rc = run(h, h->p_temb_tab, s)) return rc;
+  h->tab_count = count;
+  return 0;
+}
+
+int sdeo_ddim_step(sdeo_handle h, float* x, float* pred_x0, int table_row, float cfg_scale, float a_t, float a_prev,
+                   float sqrt_one_minus_at, const float* host_control_scales, int only_mid_control, int flags, void* stream) {
+  REQUIRE_READY(h);
+  SDEO_CHECK(x, "sdeo_ddim_step: null latent");
+  SDEO_CHECK(h->cfg.in_channels == h->cfg.out_channels, "sdeo_ddim_step: eps and latent must have the same channel count");
+  SDEO_CHECK(h->N % 2 == 0, "sdeo_ddim_step: configured for %d images; the CFG pair needs an even count (n = 2 x latents)", h->N);
+  SDEO_CHECK(table_row >= 0 && table_row < h->tab_count, "sdeo_ddim_step: timestep row %d, but the table holds %d (sdeo_set_timestep_table)",
+             table_row, h->tab_count);
+  hipStream_t s = S(stream);
+  const sdeo_config& c = h->cfg;
+  const int b = h->N / 2, HW = h->lh * h->lw;
+  int trow = -1;
+  if (int rc = select_time(h, 8 | (table_row << 8), nullptr, "sdeo_ddim_step", &trow)) return rc;
+  h->only_mid = only_mid_control;
+  for (int i = 0; i < 13; ++i) h->scales[i] = host_control_scales ? host_control_scales[i] : 1.0f;
+  if (!(flags & 16))
+    if (int rc = latent_pair_to_nhwc(h->x0.p, h->x0.ld, x, b, c.in_channels, HW, s)) return rc;
+  if (int rc = run_step_programs(h, false, true, s)) return rc;
+  return cfg_ddim_pair(x, pred_x0, h->eps16.p, h->eps16.ld, h->x0.p, h->x0.ld, b, c.out_channels, HW, cfg_scale, a_t, a_prev,
+                       sqrt_one_minus_at, s);
 }
 
 int sdeo_vae_decode(sdeo_handle h, const float* z, int n, float* images, uint8_t* images_u8, void* stream) {

@@ -11,6 +11,13 @@ from . import _lib, spec as S
 from ._lib import SdeoConfig, check, cur_stream, ptr
 
 HINT_CACHED, CONTEXT_CACHED, NO_CONTROL = 1, 2, 4
+STEP_LATENT_STAGED = 16
+
+
+def TIMESTEP_ROW(i: int) -> int:
+    """SDEO_TIMESTEP_ROW(i) of include/sdeo.h: run at row i of the table set with `set_timestep_table`"""
+    return 8 | (int(i) << 8)
+
 
 
 def make_config(ucfg: S.UNetConfig = S.UNET_SD15, vcfg: S.VAEConfig = S.VAE_SD15) -> SdeoConfig:
@@ -205,7 +212,7 @@ class SdeoRuntime:
         x = self._f32(x, (self.n, u.in_channels, self.h, self.w))
         hint = self._f32(hint, (self.n, u.hint_channels, 8 * self.h, 8 * self.w)) if hint is not None else None
         ctx = self._f32(ctx, (self.n, u.context_len, u.context_dim)) if ctx is not None else None
-        t = self._t64(t)
+        t = self._t64(t) if t is not None else None          # None: flags carry TIMESTEP_ROW(i)
         if hint is None and not (flags & HINT_CACHED):
             flags |= NO_CONTROL
         eps = out if out is not None else torch.empty((self.n, u.out_channels, self.h, self.w), dtype=torch.float32,
@@ -240,6 +247,26 @@ class SdeoRuntime:
         self._gt.copy_(t)
         self._graphs[0].replay()
         return self._geps
+
+    def set_timestep_table(self, timesteps) -> int:
+        """Hand the sampler's schedule (a host sequence of ints, in the order the loop visits them) to the library: the time
+        embeddings of both networks for every step are computed once (`sdeo_set_timestep_table`).  Returns the number of rows."""
+        ts = [int(t) for t in timesteps]
+        arr = (C.c_int64 * len(ts))(*ts)
+        check(self.lib.sdeo_set_timestep_table(self.handle, arr, C.c_int(len(ts)), cur_stream()), "set_timestep_table")
+        self._table_key = (self.generation, tuple(ts))      # whose schedule the table holds (captured graphs read it by address)
+        return len(ts)
+
+    def ddim_step(self, x, pred_x0, row: int, cfg_scale: float, a_t: float, a_prev: float, sqrt_one_minus_at: float, scales=None,
+                  only_mid_control: bool = False, staged: bool = False):
+        """`sdeo_ddim_step`: one eta = 0 DDIM step of the CFG pair; x (b,4,h,w) fp32 contiguous is updated in place."""
+        assert x.is_contiguous() and x.dtype == torch.float32 and 2 * x.shape[0] == self.n
+        assert pred_x0 is None or (pred_x0.is_contiguous() and pred_x0.dtype == torch.float32 and pred_x0.shape == x.shape)
+        check(self.lib.sdeo_ddim_step(self.handle, ptr(x), ptr(pred_x0), C.c_int(int(row)), C.c_float(cfg_scale), C.c_float(a_t),
+                                      C.c_float(a_prev), C.c_float(sqrt_one_minus_at), self._scales(scales),
+                                      C.c_int(int(only_mid_control)), C.c_int(STEP_LATENT_STAGED if staged else 0), cur_stream()),
+              "ddim_step")
+        return x
 
     def vae_decode(self, z, want_u8: bool = False):
         """z (b,4,h,w) latents (sampler output) -> images (b,3,8h,8w) fp32 in [-1,1] (+ optional NHWC uint8)."""

@@ -257,6 +257,53 @@ def test_whole_loop_graph_equals_per_step_replay(tiny_model):
         m.control_scales = [1.0] * 13
 
 
+def test_timestep_table_and_library_ddim_step(tiny_model):
+    """`sdeo_set_timestep_table` + SDEO_TIMESTEP_ROW(i): eps is bit-identical to the same forward given the timesteps themselves;
+    `sdeo_ddim_step` (apply_model on [x; x] + CFG + DDIM update inside the library) is bit-identical to sdeo_apply_model followed by
+    sdeo_cfg_ddim_step, with and without the staged-latent shortcut; rows outside the table are refused."""
+    from stablediffusioneo_amd import ops
+    from stablediffusioneo_amd._lib import SdeoError
+    from stablediffusioneo_amd.runtime import CONTEXT_CACHED, HINT_CACHED, TIMESTEP_ROW
+    m = tiny_model
+    dev = m.device
+    cd = m.rt.ucfg.context_dim
+    rt = m.rt.configure(2, 8, 16)
+    x, _, _ = make_inputs(1, 8, 16, ctx_dim=cd, x_seed=5)
+    x = x.to(dev)
+    hint = make_hint(1, 64, 128, seed=4).to(dev)
+    ctx2 = torch.cat([randn((1, 77, cd), 7), randn((1, 77, cd), 8)]).to(dev)
+    sched = [981, 601, 341, 1]
+    scales = [0.8 ** (12 - i) for i in range(13)]
+    t2 = torch.full((2,), sched[1], dtype=torch.long, device=dev)
+    ref = rt.apply_model(torch.cat([x, x]), torch.cat([hint, hint]), t2, ctx2, scales).clone()       # fills the hint / context caches
+    assert rt.set_timestep_table(sched) == 4
+    got = rt.apply_model(torch.cat([x, x]), None, None, None, scales, flags=HINT_CACHED | CONTEXT_CACHED | TIMESTEP_ROW(1)).clone()
+    assert torch.equal(got, ref)
+    with pytest.raises(SdeoError, match="table holds 4"):
+        rt.apply_model(torch.cat([x, x]), None, None, None, scales, flags=HINT_CACHED | CONTEXT_CACHED | TIMESTEP_ROW(4))
+    # two steps: library step (second one staged) vs apply_model + cfg_ddim_step
+    a_t, a_p = [0.31, 0.62], [0.62, 0.88]
+    xr = x.clone()
+    preds = []
+    for k, row in enumerate((1, 2)):
+        tk = torch.full((2,), sched[row], dtype=torch.long, device=dev)
+        e2 = rt.apply_model(torch.cat([xr, xr]), None, tk, None, scales, flags=HINT_CACHED | CONTEXT_CACHED)
+        xr, p0 = ops.cfg_ddim_step(xr, e2[:1], e2[1:], 7.5, a_t[k], a_p[k], 0.0, float(np.sqrt(1 - a_t[k])), noise=None)
+        preds.append(p0.clone())
+    for staged_second in (False, True):
+        xl, pl = x.clone(), torch.empty_like(x)
+        rt.ddim_step(xl, pl, 1, 7.5, a_t[0], a_p[0], float(np.sqrt(1 - a_t[0])), scales)
+        assert torch.equal(pl, preds[0])
+        rt.ddim_step(xl, pl, 2, 7.5, a_t[1], a_p[1], float(np.sqrt(1 - a_t[1])), scales, staged=staged_second)
+        assert torch.equal(pl, preds[1]) and torch.equal(xl, xr)
+    with pytest.raises(SdeoError, match="table holds 4"):
+        rt.ddim_step(xl, None, 9, 7.5, 0.5, 0.6, 0.7, scales)
+    rt.configure(2, 8, 8)                                   # a re-plan drops the table
+    rt.configure(2, 8, 16)
+    with pytest.raises(SdeoError, match="table holds 0"):
+        rt.ddim_step(xl, None, 0, 7.5, 0.5, 0.6, 0.7, scales)
+
+
 def test_ddim_encode_vs_oracle(tiny_model):
     """DDIMSampler.encode (DDIM inversion, `cldm/ddim_hacked.py:233-279`) against the oracle's restatement; tolerance as for
     sampling: a trajectory feeds fp16 network error back through the steps"""
