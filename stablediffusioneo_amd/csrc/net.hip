@@ -194,6 +194,7 @@ struct Op {          // one launch of a program + what it is for the profiler
   const char* key = "other";
   std::string tag;           // problem shape, shown by the profiler when SDEO_PROFILE_DETAIL=1
   double flops = 0, bytes = 0;
+  bool zero_conv = false;    // ControlNet program: a zero conv (skipped when the UNet decoder applies the zero convs itself)
   template <class F>
   Op(F f) : fn(std::move(f)) {}
   int operator()(hipStream_t s) const { return fn(s); }
@@ -264,7 +265,9 @@ struct sdeo_handle_s {
   std::vector<void*> extra_allocs;
   // persistent activations
   T ctrl[13];            // fp16 NHWC controls (ControlNet output / UNet input), unscaled
+  T cn_h[13];            // the ControlNet block outputs the zero convs read (kept until the UNet decoder has run)
   float scales[13];
+  float eff_scales[13];  // scales with only_mid_control folded in (0 for the twelve skip controls), read at launch by p_unet_dec_fused
   int only_mid = 0;
   bool use_control = true;
   // time embedding (`openaimodel.py:777-781` + every ResBlock's emb_layers): fp32 [N][emb_total] per net, written by p_temb[net] from
@@ -281,7 +284,7 @@ struct sdeo_handle_s {
   T eps16;               // the UNet's eps before the NCHW fp32 export (p_eps_export), read directly by sdeo_ddim_step
   // programs
   Program p_hint, p_ctx_cn, p_ctx_unet, p_cn, p_cn_export, p_ctrl_import, p_unet_enc, p_unet_dec, p_unet_noctrl, p_vae;
-  Program p_temb[2], p_temb_tab, p_x0, p_eps_export;
+  Program p_temb[2], p_temb_tab, p_x0, p_eps_export, p_unet_dec_fused;
   std::vector<size_t> ctrl_elems;
   size_t device_bytes = 0;
   // profiling (sdeo_profile_*): HIP events around every launch of the next programs
@@ -940,15 +943,17 @@ struct Built {
   T hint_feat;
 };
 
-static int run(Engine* e, const Program& p, hipStream_t s) {
+static int run(Engine* e, const Program& p, hipStream_t s, bool skip_zero_convs = false) {
   if (!e->profiling) {
     for (auto& op : p) {
+      if (skip_zero_convs && op.zero_conv) continue;
       if (int rc = op(s)) return rc;
     }
     return 0;
   }
   static const bool detail = [] { const char* v = getenv("SDEO_PROFILE_DETAIL"); return v && atoi(v) != 0; }();
   for (auto& op : p) {
+    if (skip_zero_convs && op.zero_conv) continue;
     ProfRec r{detail && !op.tag.empty() ? std::string(op.key) + " | " + op.tag : std::string(op.key), op.flops, op.bytes, nullptr, nullptr};
     SDEO_HIP(hipEventCreate(&r.a));
     SDEO_HIP(hipEventCreate(&r.b));
@@ -1070,6 +1075,14 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
     b.prog = &e->p_cn;
     b.arena = &arena2; b.base = e->arena2; b.ws_sel = 1;
     const std::string ns = NS_CN;
+    // The block outputs stay allocated (cn_h): sdeo_apply_model / sdeo_ddim_step skip the zero convs here and let the UNet decoder apply
+    // them with the skip connection as the residual operand (p_unet_dec_fused); sdeo_controlnet_forward runs them here (13 controls out).
+    auto zero_conv = [&](const T& x, const std::string& name, int cout, const T* out) {
+      const size_t first = e->p_cn.size();
+      Builder::CO zo; zo.out = out;
+      b.conv(x, name, cout, 1, 1, 0, zo);
+      for (size_t k = first; k < e->p_cn.size(); ++k) e->p_cn[k].zero_conv = true;
+    };
     T hcur = e->x0;
     for (size_t i = 0; i < e->cplan.in.size(); ++i) {
       T y;
@@ -1078,16 +1091,15 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
         Builder::CO o; o.res = &bt.hint_feat; o.gn_next = true;
         y = b.conv(hcur, ns + e->cplan.in[0][0].name, c.model_channels, 3, 1, 0, o);
       } else {
-        y = run_blocks(ns, e->cplan.in[i], hcur, true, 1, nullptr);
+        y = run_blocks(ns, e->cplan.in[i], hcur, false, 1, nullptr);
       }
       hcur = y;
-      Builder::CO zo; zo.out = &e->ctrl[i];
-      b.conv(hcur, ns + "zero_convs." + std::to_string(i) + ".0", e->cplan.in_ch[i], 1, 1, 0, zo);
+      e->cn_h[i] = y;
+      zero_conv(hcur, ns + "zero_convs." + std::to_string(i) + ".0", e->cplan.in_ch[i], &e->ctrl[i]);
     }
-    T m = run_blocks(ns, e->cplan.mid, hcur, true, 1, nullptr);
-    Builder::CO zo; zo.out = &e->ctrl[e->cplan.in.size()];
-    b.conv(m, ns + "middle_block_out.0", e->cplan.in_ch.back(), 1, 1, 0, zo);
-    b.release(m);
+    T m = run_blocks(ns, e->cplan.mid, hcur, false, 1, nullptr);
+    e->cn_h[e->cplan.in.size()] = m;
+    zero_conv(m, ns + "middle_block_out.0", e->cplan.in_ch.back(), &e->ctrl[e->cplan.in.size()]);
     b.arena = &arena; b.base = e->arena; b.ws_sel = 0;
   }
   const int nctrl = (int)e->cplan.in.size() + 1;
@@ -1120,51 +1132,73 @@ static void build_all(Engine* e, Arena& arena, Arena& arena2, bool dry, size_t* 
       hcur = y;
     }
     // middle block; its output goes straight into the first concat buffer
-    size_t oi = 0;
-    int ci = nctrl - 1;
     auto cat_for = [&](int c_h, const T& skip) { return b.alloc(skip.n, skip.h, skip.w, c_h + skip.c); };
-    T skip = hs.back();
-    T cat = cat_for(e->uplan.mid.back().cout, skip);
-    T view = cat; view.c = e->uplan.mid.back().cout; view.off = (size_t)-1;
-    T m = run_blocks(ns, e->uplan.mid, hcur, false, 0, &view);
-    (void)m;
-    if (with_ctrl) b.prog = &e->p_unet_dec;     // everything below needs the controls: runs after the join
-    if (with_ctrl) {   // h += control.pop()
-      f16* yp = view.p; const int ld = view.ld, rows = view.rows(), Cc = view.c;
-      const f16* cp = e->ctrl[ci].p; const int ldc = e->ctrl[ci].ld; const float* sc = &e->scales[ci];
-      b.push([=](hipStream_t s) { return add_scaled(yp, ld, yp, ld, cp, ldc, *sc, rows, Cc, s); });
-    }
-    --ci;
-    for (oi = 0; oi < e->uplan.out.size(); ++oi) {
-      // second half of the concat buffer: hs.pop() (+ control.pop() unless only_mid_control)
-      skip = hs.back();
-      hs.pop_back();
-      {
-        const int c_h = cat.c - skip.c;
-        f16* yp = cat.p + c_h; const int ld = cat.ld, rows = cat.rows(), Cc = skip.c;
-        const f16* ap = skip.p; const int lda = skip.ld;
-        const f16* cp = with_ctrl ? e->ctrl[ci].p : nullptr; const int ldc = with_ctrl ? e->ctrl[ci].ld : 0;
-        const float* sc = &e->scales[ci]; const int* om = &e->only_mid;
-        b.push([=](hipStream_t s) { return add_scaled(yp, ld, ap, lda, (*om) ? nullptr : cp, ldc, *sc, rows, Cc, s); });
+    T cat0 = cat_for(e->uplan.mid.back().cout, hs.back());
+    T view0 = cat0; view0.c = e->uplan.mid.back().cout; view0.off = (size_t)-1;
+    run_blocks(ns, e->uplan.mid, hcur, false, 0, &view0);
+    // The decoder (`openaimodel.py:797-801` with `cldm/cldm.py:33-41`): h = cat([h, hs.pop() + control.pop()]).  Three forms of the same
+    // program: no control; controls given as tensors (the 13-tensor boundary: one add per control); controls applied as the ControlNet's
+    // zero convs themselves, out = scale * zero_conv(cn_h) + skip written straight into the concat buffer (no add launches, no fp16
+    // round trip of the control).  The latter two start from the same encoder state, so the arena is rewound between them.
+    enum { D_NOCTRL, D_ADD, D_FUSED };
+    auto build_decoder = [&](int mode, std::vector<T> hs, T cat, T view) {
+      int ci = nctrl - 1;
+      if (mode == D_ADD) {   // h += control.pop()
+        f16* yp = view.p; const int ld = view.ld, rows = view.rows(), Cc = view.c;
+        const f16* cp = e->ctrl[ci].p; const int ldc = e->ctrl[ci].ld; const float* sc = &e->scales[ci];
+        b.push([=](hipStream_t s) { return add_scaled(yp, ld, yp, ld, cp, ldc, *sc, rows, Cc, s); });
+      } else if (mode == D_FUSED) {
+        Builder::CO zo; zo.out = &view; zo.res = &view; zo.scale_host = &e->eff_scales[ci];
+        b.conv(e->cn_h[ci], std::string(NS_CN) + "middle_block_out.0", view.c, 1, 1, 0, zo);
       }
       --ci;
-      b.release(skip);
-      const std::vector<Blk>& blocks = e->uplan.out[oi];
-      if (oi + 1 < e->uplan.out.size()) {
-        const T& nskip = hs.back();
-        const int c_h = blocks.back().cout;
-        const int up = blocks.back().kind == B_UP ? 2 : 1;
-        T ncat = b.alloc(cat.n, cat.h * up, cat.w * up, c_h + nskip.c);
-        T nview = ncat; nview.c = c_h; nview.off = (size_t)-1;
-        run_blocks(ns, blocks, cat, true, 0, &nview);
-        cat = ncat;
-      } else {
-        T y = run_blocks(ns, blocks, cat, true, 0, nullptr);
-        Builder::CO oo; oo.cout_store = 4 * ((c.out_channels + 3) / 4);
-        oo.out = &e->eps16;
-        b.gn_conv(y, ns + "out.0", 1e-5f, 1, ns + "out.2", c.out_channels, oo);
-        b.release(y);
+      for (size_t oi = 0; oi < e->uplan.out.size(); ++oi) {
+        // second half of the concat buffer: hs.pop() (+ control.pop() unless only_mid_control)
+        T skip = hs.back();
+        hs.pop_back();
+        const int c_h = cat.c - skip.c;
+        if (mode == D_FUSED) {
+          T half = cat; half.p = cat.p + c_h; half.c = skip.c; half.off = (size_t)-1;
+          Builder::CO zo; zo.out = &half; zo.res = &skip; zo.scale_host = &e->eff_scales[ci];
+          b.conv(e->cn_h[ci], std::string(NS_CN) + "zero_convs." + std::to_string(ci) + ".0", skip.c, 1, 1, 0, zo);
+        } else {
+          f16* yp = cat.p + c_h; const int ld = cat.ld, rows = cat.rows(), Cc = skip.c;
+          const f16* ap = skip.p; const int lda = skip.ld;
+          const f16* cp = mode == D_ADD ? e->ctrl[ci].p : nullptr; const int ldc = mode == D_ADD ? e->ctrl[ci].ld : 0;
+          const float* sc = &e->scales[ci]; const int* om = &e->only_mid;
+          b.push([=](hipStream_t s) { return add_scaled(yp, ld, ap, lda, (*om) ? nullptr : cp, ldc, *sc, rows, Cc, s); });
+        }
+        --ci;
+        b.release(skip);
+        const std::vector<Blk>& blocks = e->uplan.out[oi];
+        if (oi + 1 < e->uplan.out.size()) {
+          const T& nskip = hs.back();
+          const int c_hn = blocks.back().cout;
+          const int up = blocks.back().kind == B_UP ? 2 : 1;
+          T ncat = b.alloc(cat.n, cat.h * up, cat.w * up, c_hn + nskip.c);
+          T nview = ncat; nview.c = c_hn; nview.off = (size_t)-1;
+          run_blocks(ns, blocks, cat, true, 0, &nview);
+          cat = ncat;
+        } else {
+          T y = run_blocks(ns, blocks, cat, true, 0, nullptr);
+          Builder::CO oo; oo.cout_store = 4 * ((c.out_channels + 3) / 4);
+          oo.out = &e->eps16;
+          b.gn_conv(y, ns + "out.0", 1e-5f, 1, ns + "out.2", c.out_channels, oo);
+          b.release(y);
+        }
       }
+    };
+    if (!with_ctrl) {
+      build_decoder(D_NOCTRL, hs, cat0, view0);
+    } else {
+      const Arena after_encoder = arena;          // everything below needs the controls: runs after the join
+      b.prog = &e->p_unet_dec;
+      build_decoder(D_ADD, hs, cat0, view0);
+      const size_t peak_add = arena.peak;
+      arena = after_encoder;
+      arena.peak = std::max(arena.peak, peak_add);
+      b.prog = &e->p_unet_dec_fused;
+      build_decoder(D_FUSED, hs, cat0, view0);
     }
   }
 
@@ -1294,7 +1328,7 @@ static void free_configured(Engine* e) {
   if (e->arena2) (void)hipFree(e->arena2);
   e->arena2 = nullptr;
   for (Program* p : {&e->p_hint, &e->p_ctx_cn, &e->p_ctx_unet, &e->p_cn, &e->p_cn_export, &e->p_ctrl_import, &e->p_unet_enc,
-                     &e->p_unet_dec, &e->p_unet_noctrl, &e->p_vae, &e->p_temb[0], &e->p_temb[1], &e->p_temb_tab, &e->p_x0, &e->p_eps_export})
+                     &e->p_unet_dec, &e->p_unet_noctrl, &e->p_vae, &e->p_temb[0], &e->p_temb[1], &e->p_temb_tab, &e->p_x0, &e->p_eps_export, &e->p_unet_dec_fused})
     p->clear();
   e->tab_count = 0;
 }
@@ -1601,6 +1635,12 @@ static int select_time(sdeo_handle h, int flags, const int64_t* timesteps, const
   return 0;
 }
 
+// only_mid_control (`cldm/cldm.py:35-41`): the twelve skip controls are dropped, the middle one stays
+static void set_effective_scales(sdeo_handle h) {
+  const int mid = (int)h->cplan.in.size();
+  for (int i = 0; i < 13; ++i) h->eff_scales[i] = (h->only_mid && i != mid) ? 0.0f : h->scales[i];
+}
+
 // ControlNet || UNet encoder, join, UNet decoder: eps16 holds the result.  The latent is already in x0.
 static int run_step_programs(sdeo_handle h, bool no_control, bool time_from_table, hipStream_t s) {
   if (no_control) {
@@ -1612,7 +1652,7 @@ static int run_step_programs(sdeo_handle h, bool no_control, bool time_from_tabl
     SDEO_HIP(hipEventRecord(h->ev_fork, s));
     SDEO_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
     if (!time_from_table) if (int rc = run(h, h->p_temb[1], h->side)) return rc;
-    if (int rc = run(h, h->p_cn, h->side)) return rc;
+    if (int rc = run(h, h->p_cn, h->side, true)) return rc;
     SDEO_HIP(hipEventRecord(h->ev_join, h->side));
     if (!time_from_table) if (int rc = run(h, h->p_temb[0], s)) return rc;
     if (int rc = run(h, h->p_unet_enc, s)) return rc;
@@ -1622,10 +1662,10 @@ static int run_step_programs(sdeo_handle h, bool no_control, bool time_from_tabl
       if (int rc = run(h, h->p_temb[1], s)) return rc;
       if (int rc = run(h, h->p_temb[0], s)) return rc;
     }
-    if (int rc = run(h, h->p_cn, s)) return rc;
+    if (int rc = run(h, h->p_cn, s, true)) return rc;
     if (int rc = run(h, h->p_unet_enc, s)) return rc;
   }
-  return run(h, h->p_unet_dec, s);
+  return run(h, h->p_unet_dec_fused, s);      // applies the zero convs itself (skipped above)
 }
 
 int sdeo_controlnet_forward(sdeo_handle h, const float* x_noisy, const float* hint, const int64_t* timesteps,
@@ -1693,6 +1733,7 @@ int sdeo_apply_model(sdeo_handle h, const float* x_noisy, const float* hint, con
     return rc;
   h->only_mid = only_mid_control;
   for (int i = 0; i < 13; ++i) h->scales[i] = host_control_scales ? host_control_scales[i] : 1.0f;
+  set_effective_scales(h);
   if (int rc = run(h, h->p_x0, s)) return rc;
   if (int rc = run_step_programs(h, no_control, trow >= 0, s)) return rc;
   if (int rc = run(h, h->p_eps_export, s)) return rc;
@@ -1729,6 +1770,7 @@ int sdeo_ddim_step(sdeo_handle h, float* x, float* pred_x0, int table_row, float
   if (int rc = select_time(h, 8 | (table_row << 8), nullptr, "sdeo_ddim_step", &trow)) return rc;
   h->only_mid = only_mid_control;
   for (int i = 0; i < 13; ++i) h->scales[i] = host_control_scales ? host_control_scales[i] : 1.0f;
+  set_effective_scales(h);
   if (!(flags & 16))
     if (int rc = latent_pair_to_nhwc(h->x0.p, h->x0.ld, x, b, c.in_channels, HW, s)) return rc;
   if (int rc = run_step_programs(h, false, true, s)) return rc;
