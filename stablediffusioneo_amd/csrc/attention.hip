@@ -45,6 +45,27 @@ struct AP {
 
 struct AP2 { AP k[1]; };
 
+// lane ^ 32 exchange on the VALU (gfx950 v_permlane32_swap): after the swap the pair (lo, hi) holds the value of lanes 0..31 and
+// of lanes 32..63 in every lane, so a reduction over the two halves needs no LDS round trip (ds_bpermute) in the softmax chain.
+// Inline asm, not __builtin_amdgcn_permlane32_swap: hipcc 7.2 maps both results of the builtin to ONE register for float users
+// (r0 + r1 is emitted as v_add v1, v1, v1).  The s_nop covers the VALU-write -> permlane read hazard the compiler cannot see.
+__device__ __forceinline__ void swap32(float v, float& lo, float& hi) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  lo = a;
+  hi = b;
+}
+__device__ __forceinline__ float xor32_max(float v) {
+  float lo, hi;
+  swap32(v, lo, hi);
+  return fmaxf(lo, hi);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  float lo, hi;
+  swap32(v, lo, hi);
+  return lo + hi;
+}
+
 // KS = 1: four waves, each owning 32 queries and walking all keys.  KS = 2 ("key split"): eight waves, the two waves of a
 // pair own the same 32 queries and each takes one 32-key half of every staged tile, so the serial per-tile chain
 // (QK^T -> max -> exp -> PV) per wave halves and twice as many waves hide it; the two partial (m, l, O) states are merged
@@ -89,6 +110,12 @@ void attention_kernel(const AP2 pp) {
   const int qrow = q0 + lq;
   const bool qvalid = qrow < p.Tq;
   const int d = p.d;
+  // loop-invariant scalars pinned in SGPRs (otherwise re-read from the kernel-argument segment inside the key loop, an
+  // s_load + lgkmcnt(0) in the softmax chain of every tile)
+  float sl2 = p.scale_log2;
+  int Tk = p.Tk;
+  int causal = p.causal;
+  asm volatile("" : "+s"(sl2), "+s"(Tk), "+s"(causal));
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[qrow][ks*16 + 8*lh + 0..7]
   f16x8 qf[D16];
@@ -107,37 +134,34 @@ void attention_kernel(const AP2 pp) {
   const int ntiles = (p.Tk + 63) / 64;
   const f16x8 zero8 = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
 
-  // per-thread staging state, hoisted out of the key loop: source pointers (advanced by one tile per call) and LDS
-  // destinations of the 16-byte chunks this thread moves
+  // per-thread staging state, hoisted out of the key loop: source column and LDS destinations of the 16-byte chunks this thread moves.
   // DEEP: two register sets, the loads of a tile are issued TWO tiles ahead (small head dims, where a tile's compute is
-  // shorter than a global round trip); otherwise one set, loads issued at the top of the previous tile
+  // shorter than a global round trip); otherwise one set, loads issued at the top of the previous tile.
+  // Every load is UNCONDITIONAL (rows past Tk read row Tk - 1 again: those keys are masked to -inf, so P is 0 against a finite
+  // V; threads without a chunk read chunk 0 and never store): with loads under exec masks or uniform branches the compiler
+  // cannot count them and turns every wait into vmcnt(0), which serialises the prefetch with the compute it should hide behind.
   constexpr bool DEEP = D16 <= 5;
   f16x8 kr[DEEP ? 2 : 1][KPASS], vr[DEEP ? 2 : 1][KPASS];
-  const f16* kptr[KPASS];
-  const f16* vptr[KPASS];
-  int krow[KPASS], kdst[KPASS], vdst[KPASS];
+  int krow[KPASS], kcol[KPASS], kdst[KPASS], vdst[KPASS];
 #pragma unroll
   for (int i = 0; i < KPASS; ++i) {
     const int it = tid + i * NT;
     const int row = it / KCH, c = it - row * KCH;
     const bool use = it < KITEMS && c * 8 < d;
-    krow[i] = use ? row : (1 << 30);                 // never valid
-    kptr[i] = kbase + (size_t)row * p.ldk + c * 8;
-    vptr[i] = vbase + (size_t)row * p.ldv + c * 8;
-    kdst[i] = it < KITEMS ? row * KROW + c * 16 : -1;
-    vdst[i] = use ? row * VROW + c * 16 : -1;        // chunk slots past d keep their zeros / the ones column
+    krow[i] = row;
+    kcol[i] = use ? c * 8 : 0;
+    kdst[i] = use ? row * KROW + c * 16 : -1;        // chunk slots past d keep their zeros (K) / zeros and the ones column (V)
+    vdst[i] = use ? row * VROW + c * 16 : -1;
   }
-  const size_t kstep = (size_t)64 * p.ldk, vstep = (size_t)64 * p.ldv;
+  const int last_key = Tk - 1;
   auto load_tile = [&](auto SET, int kt) {
     constexpr int rs = SET.value;
     const int key0 = kt * 64;
 #pragma unroll
     for (int i = 0; i < KPASS; ++i) {
-      const bool ok = key0 + krow[i] < p.Tk;        // rows >= Tk: K zero (masked anyway), V zero (P is 0 there, V must be finite)
-      kr[rs][i] = ok ? *reinterpret_cast<const f16x8*>(kptr[i]) : zero8;
-      vr[rs][i] = ok ? *reinterpret_cast<const f16x8*>(vptr[i]) : zero8;
-      kptr[i] += kstep;
-      vptr[i] += vstep;
+      const int row = min(key0 + krow[i], last_key);
+      kr[rs][i] = *reinterpret_cast<const f16x8*>(kbase + (size_t)row * p.ldk + kcol[i]);
+      vr[rs][i] = *reinterpret_cast<const f16x8*>(vbase + (size_t)row * p.ldv + kcol[i]);
     }
   };
   auto store_tile = [&](auto SET, int stage) {
@@ -152,9 +176,8 @@ void attention_kernel(const AP2 pp) {
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
-  // the V tiles start as zeros (+ the ones column): staging only ever writes the chunk slots below d
-  for (int st = 0; st < 2; ++st)
-    for (int off = tid * 16; off < VBYTES; off += NT * 16) *reinterpret_cast<f16x8*>(smem + st * STAGE + KBYTES + off) = zero8;
+  // both stages start as zeros (+ the ones column of V): staging only ever writes the chunk slots below d
+  for (int off = tid * 16; off < 2 * STAGE; off += NT * 16) *reinterpret_cast<f16x8*>(smem + off) = zero8;
   __syncthreads();
   if (ONES && tid < 128) *reinterpret_cast<f16*>(smem + (tid >> 6) * STAGE + KBYTES + (tid & 63) * VROW + R1 * 2) = (f16)1.f;
 
@@ -167,9 +190,14 @@ void attention_kernel(const AP2 pp) {
 
   load_tile(S0{}, 0);
   store_tile(S0{}, 0);
+  // a use of the Q fragments HERE, before the prefetch loads are issued: their wait is then placed in front of the loop.  Left
+  // to its first real use (the first MFMA of the loop) the compiler must assume Q still in flight on every iteration and waits
+  // vmcnt(0) at the top of each tile, which serialises the prefetched K / V loads with the compute they were meant to hide behind.
+#pragma unroll
+  for (int ks = 0; ks < D16; ++ks) asm volatile("" ::"v"(qf[ks]));
   if constexpr (DEEP) {
-    if (ntiles > 1) load_tile(S1{}, 1);             // set 1 carries the odd tiles, set 0 the even ones
-    if (ntiles > 2) load_tile(S0{}, 2);
+    load_tile(S1{}, 1);                             // set 1 carries the odd tiles, set 0 the even ones
+    load_tile(S0{}, 2);
   }
   __syncthreads();
 
@@ -195,21 +223,24 @@ void attention_kernel(const AP2 pp) {
     }
     // ---- online softmax (base-2), key index of s[kb][r] = kt*64 + kb*32 + (r&3) + 8*(r>>2) + 4*lh
     //      the running max is kept in scaled units (score * scale * log2 e); the scale itself is folded into one fma
-    const bool tail = (kt + 1) * 64 > p.Tk || p.causal;
+    // masking only on a tile that needs it: ONE uniform branch per tile (inside the register loop it became a branch per score register)
+    if ((kt + 1) * 64 > Tk || causal) {
+#pragma unroll
+      for (int ki = 0; ki < NKB; ++ki)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kb = KS == 2 ? kh : ki;
+          const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key >= Tk || (causal && key > qrow)) s[ki][r] = -INFINITY;
+        }
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int ki = 0; ki < NKB; ++ki)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (tail) {
-          const int kb = KS == 2 ? kh : ki;
-          const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (key >= p.Tk || (p.causal && key > qrow)) s[ki][r] = -INFINITY;
-        }
-        mx = fmaxf(mx, s[ki][r]);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * p.scale_log2);
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[ki][r]);
+    mx = xor32_max(mx);
+    const float m_new = fmaxf(m_run, mx * sl2);
     // a key half that has not seen a single valid key yet (KS == 2, Tk <= 32) keeps m = -inf: exponentiate against 0
     const float m_use = (KS == 2 && m_new == -INFINITY) ? 0.f : m_new;
     float rs = 0.f;
@@ -217,11 +248,11 @@ void attention_kernel(const AP2 pp) {
     for (int ki = 0; ki < NKB; ++ki)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(s[ki][r], p.scale_log2, -m_use));
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[ki][r], sl2, -m_use));
         s[ki][r] = pv;
         if (!ONES) rs += pv;
       }
-    if (!ONES) rs += __shfl_xor(rs, 32, 64);
+    if (!ONES) rs = xor32_sum(rs);
     if (__any(m_new > m_run)) {      // wave-uniform: after the first few tiles the running max rarely moves
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
@@ -258,25 +289,22 @@ void attention_kernel(const AP2 pp) {
   if constexpr (DEEP) {
     // at the end of a tile the NEXT tile (loaded two iterations ago) goes from registers to the other LDS buffer and the freed
     // register set takes the loads of the tile after that: a global round trip has two tiles of compute to hide behind
-    for (int kt = 0; kt < ntiles; kt += 2) {
+    for (int kt = 0; kt < ntiles; kt += 2) {      // an odd tile count runs one fully masked tile (P = 0) at the end
       compute(kt, 0);
-      if (kt + 1 < ntiles) store_tile(S1{}, 1);
-      if (kt + 3 < ntiles) load_tile(S1{}, kt + 3);
+      store_tile(S1{}, 1);
+      load_tile(S1{}, kt + 3);
       __syncthreads();
-      if (kt + 1 < ntiles) {
-        compute(kt + 1, 1);
-        if (kt + 2 < ntiles) store_tile(S0{}, 0);
-        if (kt + 4 < ntiles) load_tile(S0{}, kt + 4);
-        __syncthreads();
-      }
+      compute(kt + 1, 1);
+      store_tile(S0{}, 0);
+      load_tile(S0{}, kt + 4);
+      __syncthreads();
     }
   } else {
     for (int kt = 0; kt < ntiles; ++kt) {
       const int cur = kt & 1;
-      const bool more = kt + 1 < ntiles;
-      if (more) load_tile(S0{}, kt + 1);
+      load_tile(S0{}, kt + 1);
       compute(kt, cur);
-      if (more) store_tile(S0{}, cur ^ 1);
+      store_tile(S0{}, cur ^ 1);
       __syncthreads();
     }
   }
@@ -461,7 +489,7 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(const AP p) {
       if (tail && kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh >= p.Tk) s[r] = -INFINITY;
       mx = fmaxf(mx, s[r]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = xor32_max(mx);
     const float m_new = fmaxf(m_run, mx * p.scale_log2);       // tile 0 always holds key 0: finite from the first tile on
     float rs = 0.f;
 #pragma unroll
@@ -470,7 +498,7 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(const AP p) {
       s[r] = pv;
       rs += pv;
     }
-    rs += __shfl_xor(rs, 32, 64);
+    rs = xor32_sum(rs);
     {
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       l_run = l_run * alpha + rs;
