@@ -55,10 +55,17 @@ __device__ __forceinline__ void swap32(float v, float& lo, float& hi) {
   lo = a;
   hi = b;
 }
+// v_max_f32 without the canonicalising v_max v, v, v the compiler puts in front of fmaxf on values it cannot prove quiet
+// (results of inline asm, loop-carried state); the operands here are never signalling NaNs
+__device__ __forceinline__ float max_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float xor32_max(float v) {
   float lo, hi;
   swap32(v, lo, hi);
-  return fmaxf(lo, hi);
+  return max_raw(lo, hi);
 }
 __device__ __forceinline__ float xor32_sum(float v) {
   float lo, hi;
@@ -149,19 +156,23 @@ void attention_kernel(const AP2 pp) {
     const int row = it / KCH, c = it - row * KCH;
     const bool use = it < KITEMS && c * 8 < d;
     krow[i] = row;
-    kcol[i] = use ? c * 8 : 0;
+    kcol[i] = use ? c * 16 : 0;                      // bytes
     kdst[i] = use ? row * KROW + c * 16 : -1;        // chunk slots past d keep their zeros (K) / zeros and the ones column (V)
     vdst[i] = use ? row * VROW + c * 16 : -1;
   }
   const int last_key = Tk - 1;
+  // byte offsets from the (wave-uniform) head bases stay below 2^32 and their factors below 2^24: one v_mad_u32_u24 per
+  // address and the scalar-base form of global_load instead of a 64-bit multiply-add chain per load
+  unsigned ldk2 = (unsigned)p.ldk * 2u, ldv2 = (unsigned)p.ldv * 2u;
+  asm volatile("" : "+s"(ldk2), "+s"(ldv2));
   auto load_tile = [&](auto SET, int kt) {
     constexpr int rs = SET.value;
     const int key0 = kt * 64;
 #pragma unroll
     for (int i = 0; i < KPASS; ++i) {
-      const int row = min(key0 + krow[i], last_key);
-      kr[rs][i] = *reinterpret_cast<const f16x8*>(kbase + (size_t)row * p.ldk + kcol[i]);
-      vr[rs][i] = *reinterpret_cast<const f16x8*>(vbase + (size_t)row * p.ldv + kcol[i]);
+      const unsigned row = (unsigned)min(key0 + krow[i], last_key);
+      kr[rs][i] = *reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(kbase) + (__umul24(row, ldk2) + (unsigned)kcol[i]));
+      vr[rs][i] = *reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(vbase) + (__umul24(row, ldv2) + (unsigned)kcol[i]));
     }
   };
   auto store_tile = [&](auto SET, int stage) {
@@ -239,10 +250,24 @@ void attention_kernel(const AP2 pp) {
     for (int ki = 0; ki < NKB; ++ki)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[ki][r]);
-    mx = xor32_max(mx);
-    const float m_new = fmaxf(m_run, mx * sl2);
+    mx = xor32_max(mx) * sl2;
+    // Lazy rescale: the running reference m_run moves only when some row's new maximum exceeds it by more than 8 (base-2 units),
+    // i.e. P = 2^(s - m_run) stays below 2^8 -- exact in the fp32 accumulators and far inside fp16 for the P V operand.  The
+    // result is the same softmax (any common reference per row cancels in O / l); with the eager form ~70 % of the tiles of a
+    // 32-query block took the 19-instruction rescale of O on random scores, with this one only the first few do.
+    if (__any(mx > m_run + 8.0f)) {    // wave-uniform; -inf + 8 = -inf, so the first valid tile always takes it
+      const float m_new = max_raw(m_run, mx);
+      // a row that has not seen a valid key yet (m_new = -inf; its O and l are still 0) must not form -inf - -inf
+      const float alpha = m_new == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      m_run = m_new;
+    }
     // a key half that has not seen a single valid key yet (KS == 2, Tk <= 32) keeps m = -inf: exponentiate against 0
-    const float m_use = (KS == 2 && m_new == -INFINITY) ? 0.f : m_new;
+    const float m_use = (KS == 2 && m_run == -INFINITY) ? 0.f : m_run;
     float rs = 0.f;
 #pragma unroll
     for (int ki = 0; ki < NKB; ++ki)
@@ -253,15 +278,6 @@ void attention_kernel(const AP2 pp) {
         if (!ONES) rs += pv;
       }
     if (!ONES) rs = xor32_sum(rs);
-    if (__any(m_new > m_run)) {      // wave-uniform: after the first few tiles the running max rarely moves
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      l_run *= alpha;
-#pragma unroll
-      for (int t = 0; t < DT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-      m_run = m_new;
-    }
     l_run += rs;
 
     // ---- O^T += V^T P^T : P^T fragments straight from the score registers

@@ -10,6 +10,7 @@
 #         profile[:flags]   per-(kernel, shape) table of one eagerly profiled image (in-library HIP events) -> profile_<n>.json
 #         kt                rocprofv3 --kernel-trace --stats of the bench command -> kernel_stats.csv, timeline.txt
 #         gemm_counters     per-shape SQ / FETCH / WRITE counter passes (tools/gemm_counters.py) -> gemm_counters.json
+#         attn_counters     SQ counter passes on the T = 4096, d = 40 self-attention (tools/one_attn.py) -> attn_counters.json
 #         step_counters     whole-step counter passes, eager + one stream (tools/step_counters.py) -> step_counters.json
 #         pmc_graph_only / pmc_overlap_only   one --pmc pass of a 2-step sampler run with ONLY graph replay / ONLY the side stream on
 #         py:<script>[,args] python <script> args                          -> py_<n>.log
@@ -43,6 +44,12 @@ s_gemm_counters() {
   pmc_pass gc_write tools/gemm_counters.py WRITE_SIZE || return $?
   python tools/gemm_counters_summary.py $OUT/gemm_counters.json $(find $OUT/pmc_gc_* -name "*.db") > $OUT/gemm_counters.txt 2>&1; cat $OUT/gemm_counters.txt
   find $OUT/pmc_gc_* -name "*.db" -size +20M -delete; return 0; }
+s_attn_counters() {
+  pmc_pass ac_sq "tools/one_attn.py 4096 40 6" SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES || return $?
+  pmc_pass ac_sq2 "tools/one_attn.py 4096 40 6" SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS || return $?
+  pmc_pass ac_sq3 "tools/one_attn.py 4096 40 6" SQ_WAVES SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL || return $?
+  python tools/gemm_counters_summary.py $OUT/attn_counters.json $(find $OUT/pmc_ac_* -name "*.db") > $OUT/attn_counters.txt 2>&1; cat $OUT/attn_counters.txt
+  find $OUT/pmc_ac_* -name "*.db" -size +20M -delete; return 0; }
 s_step_counters() {
   pmc_pass fetch "tools/step_counters.py 512 vae" FETCH_SIZE || return $?
   pmc_pass write "tools/step_counters.py 512 vae" WRITE_SIZE || return $?
@@ -70,6 +77,7 @@ for st in "$@"; do
     kt) step kt s_kt ;;
     gemm_counters) step gemm_counters s_gemm_counters ;;
     step_counters) step step_counters s_step_counters ;;
+    attn_counters) step attn_counters s_attn_counters ;;
     pmc_graph_only) step pmc_graph_only s_pmc_mode graph_only ;;
     pmc_overlap_only) step pmc_overlap_only s_pmc_mode overlap_only ;;
     pmc_both) step pmc_both s_pmc_mode both ;;
