@@ -232,6 +232,24 @@ void attention_kernel(const AP2 pp) {
         s[ki] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[ki], 0, 0, 0);
       }
     }
+    // ---- V^T fragments of this tile, fetched NOW (transposing LDS reads): their latency passes under the softmax below
+    //      instead of in front of every P V MFMA.  Lane (q = (lane & 15) >> 2, pp = lane & 3) of each 16-lane group addresses key
+    //      row q, channels 4pp..4pp+3 of the group's 4-key x 16-channel block and receives its own channel for the four keys.
+    f16x8 vf[NKB][2][DT];
+#pragma unroll
+    for (int ki = 0; ki < NKB; ++ki)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const int kb = KS == 2 ? kh : ki;
+        const char* vblk = vs_ + (kb * 32 + 16 * st + 4 * lh + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+          typedef __attribute__((address_space(3))) h16x4* lds_h4;
+          const h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(vblk + t * 64));
+          const h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(vblk + t * 64 + 8 * VROW));
+          vf[ki][st][t] = __builtin_shufflevector(__builtin_bit_cast(f16x4, lo), __builtin_bit_cast(f16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      }
     // ---- online softmax (base-2), key index of s[kb][r] = kt*64 + kb*32 + (r&3) + 8*(r>>2) + 4*lh
     //      the running max is kept in scaled units (score * scale * log2 e); the scale itself is folded into one fma
     // masking only on a tile that needs it: ONE uniform branch per tile (inside the register loop it became a branch per score register)
@@ -285,21 +303,11 @@ void attention_kernel(const AP2 pp) {
     for (int ki = 0; ki < NKB; ++ki)
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
-        const int kb = KS == 2 ? kh : ki;
         f16x8 pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (f16)s[ki][8 * st + j];
-        // V^T fragment by transposing reads: lane (q = (lane & 15) >> 2, pp = lane & 3) of each 16-lane group addresses key row
-        // q, channels 4pp..4pp+3 of the group's 4-key x 16-channel block and receives its own channel for the four keys
-        const char* vblk = vs_ + (kb * 32 + 16 * st + 4 * lh + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 #pragma unroll
-        for (int t = 0; t < DT; ++t) {
-          typedef __attribute__((address_space(3))) h16x4* lds_h4;
-          const h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(vblk + t * 64));
-          const h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4)(vblk + t * 64 + 8 * VROW));
-          const f16x8 vf = __builtin_shufflevector(__builtin_bit_cast(f16x4, lo), __builtin_bit_cast(f16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
-          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
-        }
+        for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[ki][st][t], pf, o[t], 0, 0, 0);
       }
   };
   if constexpr (DEEP) {
