@@ -448,6 +448,46 @@ int fold_layernorm(f16* w_out, float* s_out, float* b_out, const f16* w, const f
   return 0;
 }
 
+// ---- ff.net.2 followed by the SpatialTransformer's proj_out (`attention.py:75-76,385`, `:431-450`): two Linear maps with nothing
+//      but a residual add between them, so   proj_out(ff2(g) + t) = g (Wp W2)^T + t Wp^T + (Wp b2 + bp)
+//      is ONE GEMM over the row-concatenated operand [g | t] against  w_out[n] = [ (Wp W2)[n][0..K2) | Wp[n][0..C) ]  (built once, at
+//      weight finalisation, in fp32 from the fp16 matrices the network would otherwise stream; rounded to fp16 once).
+//      grid (ceil((K2 + C) / 256), C): thread (k, n); the bias row is blockIdx.x == gridDim.x - 1's extra duty.
+__global__ __launch_bounds__(256) void compose_proj_kernel(f16* __restrict__ w_out, float* __restrict__ b_out, const f16* __restrict__ wp,
+                                                           const float* __restrict__ bp, const f16* __restrict__ w2,
+                                                           const float* __restrict__ b2, int C, int K2) {
+  const int n = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const f16* wrow = wp + (size_t)n * C;
+  if (k < K2) {
+    float acc = 0.f;
+    for (int j = 0; j < C; ++j) acc = fmaf((float)wrow[j], (float)w2[(size_t)j * K2 + k], acc);
+    w_out[(size_t)n * (K2 + C) + k] = (f16)acc;
+  } else if (k < K2 + C) {
+    w_out[(size_t)n * (K2 + C) + k] = wrow[k - K2];
+  }
+  if (blockIdx.x == gridDim.x - 1) {            // bias: one block-wide deterministic sum per output row
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int j = threadIdx.x; j < C; j += 256) acc = fmaf((float)wrow[j], b2[j], acc);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) b_out[n] = red[0] + bp[n];
+  }
+}
+
+int compose_proj(f16* w_out, float* b_out, const f16* wp, const float* bp, const f16* w2, const float* b2, int C, int K2,
+                 hipStream_t stream) {
+  SDEO_CHECK(w_out && b_out && wp && bp && w2 && b2 && C > 0 && K2 > 0, "compose_proj: bad operand");
+  hipLaunchKernelGGL(compose_proj_kernel, dim3(cdiv(K2 + C, 256), C), dim3(256), 0, stream, w_out, b_out, wp, bp, w2, b2, C, K2);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
 // per-row (sum, sum of squares) of [rows][C] fp16 as ONE partial per row: stats[r][ld][2] (fallback producer of the
 // LayerNorm statistics when the GEMM that wrote x ran split-K)
 __global__ __launch_bounds__(256) void row_stats_kernel(float* __restrict__ stats, int ld, const f16* __restrict__ x, int ldx,

@@ -171,6 +171,9 @@ int row_stats(float* stats, int ld, const f16* x, int ldx, int rows, int C, hipS
 // fp8 weight pack: q[r][0:cols] = e4m3fn codes of w[r] / scale[r] (scale = power of two, absmax / scale <= 448) and w <- code * scale
 int quantize_fp8_rows(uint8_t* q, float* scale, f16* w, int rows, int cols, int ldw, int ldq, hipStream_t stream);
 int row_sums_f16(float* s_out, const f16* w, int rows, int C, hipStream_t stream);
+// [ (Wp W2) | Wp ] and Wp b2 + bp: ff.net.2 and proj_out of a SpatialTransformer as one Linear over [g | t] (elementwise.hip)
+int compose_proj(f16* w_out, float* b_out, const f16* wp, const float* bp, const f16* w2, const float* b2, int C, int K2,
+                 hipStream_t stream);
 // block-scaled fp8 pack of a [rows][cols] fp16 matrix (cols % 32 == 0): per 32 consecutive elements of a row one e8m0 scale byte
 // (2^(s - 127): the smallest power of two with amax / scale <= 448; 127 for an all-zero block) and 32 e4m3fn codes of x / scale
 int quantize_mx(uint8_t* q, uint8_t* scales, const f16* x, int rows, int cols, int ldx, int ldq, int lds, hipStream_t stream);

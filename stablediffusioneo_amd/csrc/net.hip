@@ -205,6 +205,8 @@ struct ProfRec { std::string key; double flops, bytes; hipEvent_t a, b; };
 
 // LayerNorm folded into a Linear at weight-finalisation time (fold_layernorm): offsets into the weight slab
 struct FoldJob { size_t w_out, s_out, b_out, w_in; std::string gamma, beta, bias; int rows, C; };
+// ff.net.2 and proj_out of one SpatialTransformer composed into one [C][5C] Linear at weight-finalisation time (compose_proj)
+struct ComposeJob { size_t w_out, b_out; std::string wp, bp, w2, b2; int C; };
 // a [rows][cols] fp16 matrix of the UNet / ControlNet that a conv / GEMM streams as its weight operand: with fp8 weights
 // (sdeo_set_weight_precision) it gets an e4m3fn copy + per-row scales and its fp16 copy is replaced by the dequantised values
 struct QRegion { size_t off; int rows, cols; size_t q_off, s_off; };
@@ -220,6 +222,7 @@ struct sdeo_handle_s {
   std::unordered_map<std::string, int> windex;
   std::unordered_map<std::string, size_t> named_off;   // extra named regions (stacked parents, LayerNorm-folded copies)
   std::vector<FoldJob> folds;
+  std::vector<ComposeJob> composes;
   std::vector<QRegion> qregions;
   std::unordered_map<size_t, int> qindex;              // fp16 slab offset -> qregions index
   int weight_bits = 16;                                // 8: fp8 e4m3fn weights for the UNet / ControlNet matrices
@@ -400,6 +403,15 @@ static void reg_attn(Registry& r, const std::string& ns, const Blk& b, int ctx) 
   r.norm(t + ".norm2", c);
   r.norm(t + ".norm3", c);
   r.conv(p + ".proj_out", c, c, 1);
+  // ff.net.2 + proj_out as one Linear over [GEGLU output | tok2] (build_attn); no fp8 / block-scaled copy: the reference modules the
+  // fp8 goldens come from round ff.net.2 and proj_out separately, and this product is formed from exactly those rounded values
+  ComposeJob cj;
+  cj.w_out = r.take((size_t)c * 5 * c * 2);
+  cj.b_out = r.take((size_t)c * 4);
+  cj.wp = p + ".proj_out.weight"; cj.bp = p + ".proj_out.bias"; cj.w2 = t + ".ff.net.2.weight"; cj.b2 = t + ".ff.net.2.bias"; cj.C = c;
+  r.e->named_off[t + ".ffproj.w"] = cj.w_out;
+  r.e->named_off[t + ".ffproj.b"] = cj.b_out;
+  r.e->composes.push_back(cj);
 }
 
 static int plan_emb_total(const UPlan& p) {
@@ -522,6 +534,8 @@ struct ConvOpts {                     // conv / gemm options
   // GroupNorm(32) (+ SiLU) of the conv's INPUT applied inside the conv kernel (Builder::gn_conv decides): the partials of x, gamma / beta
   const float* gn_in = nullptr; int gn_in_slots = 0; const float* gn_gamma = nullptr; const float* gn_beta = nullptr;
   float gn_in_eps = 1e-5f; int gn_in_silu = 0;
+  // conv(): stream this [cout][k*k*x.c] matrix / bias instead of the tensors registered under `name` (a composed Linear)
+  const f16* w_ovr = nullptr; const float* b_ovr = nullptr;
 };
 
 struct Builder {
@@ -684,7 +698,7 @@ struct Builder {
 
   // conv on an image view; weights by name (".weight"/".bias" appended)
   T conv(const T& x, const std::string& name, int cout, int k, int stride, int ups, const CO& o = CO()) {
-    const WEntry* w = W(name + ".weight");
+    const WEntry* w = o.w_ovr ? nullptr : W(name + ".weight");
     ConvGemm p;
     const int pad = k / 2;
     const int hv = ups ? 2 * x.h : x.h, wv = ups ? 2 * x.w : x.w;
@@ -692,7 +706,8 @@ struct Builder {
     const int cs = o.cout_store > 0 ? o.cout_store : cout;
     T y = o.out ? *o.out : alloc(x.n, ho, wo, cs);
     if (w && w->ipad != x.c && err.empty()) err = "conv " + name + ": input has " + std::to_string(x.c) + " channels, weight expects " + std::to_string(w->ipad);
-    p.x = x.p; p.w = wptr(name + ".weight"); p.y = y.p; p.bias = vptr(name + ".bias");
+    p.x = x.p; p.y = y.p;
+    if (o.w_ovr) { p.w = o.w_ovr; p.bias = o.b_ovr; } else { p.w = wptr(name + ".weight"); p.bias = vptr(name + ".bias"); }
     p.bias2 = o.bias2; p.ld_bias2 = o.ld_bias2;
     if (o.res) { p.res = o.res->p; p.ldres = o.res->ld; }
     p.B = x.n; p.Hi = x.h; p.Wi = x.w; p.Cin = x.c; p.Ho = ho; p.Wo = wo; p.R = p.S = k; p.stride = stride; p.pad = pad; p.ups = ups;
@@ -881,24 +896,44 @@ static T build_attn(Builder& b, const std::string& ns, const Blk& blk, const T& 
   T o2 = b.alloc(x.n, x.h, x.w, C);
   b.attn(o2, q2.p, C, kv.kv.p, 2 * C, kv.kv.p + C, 2 * C, N, H, Tq, c.context_len, TkS, TkS, d);
   b.release(q2);
+  // ff.net.2 and proj_out are two Linear maps with only the residual add between them: composed at finalisation into ONE [C][5C]
+  // matrix over the row-concatenated operand [GEGLU output (4C) | tok2 (C)] (ComposeJob), so attn2.to_out writes tok2 into the last C
+  // columns of that operand, the GEGLU GEMM writes the first 4C, and one GEMM replaces two launches (SDEO_COMPOSE_FF=0: the two-launch form)
+  static const bool compose = [] { const char* v = getenv("SDEO_COMPOSE_FF"); return !v || atoi(v) != 0; }();
+  T cat, ggv, tok2v;
+  if (compose) {
+    cat = b.alloc(x.n, x.h, x.w, 5 * C);
+    ggv = cat; ggv.c = 4 * C; ggv.off = (size_t)-1;
+    tok2v = cat; tok2v.p = cat.p + 4 * C; tok2v.c = C; tok2v.off = (size_t)-1;
+  }
   Builder::CO r2; r2.res = &tok1; r2.stats = &st2;
+  if (compose) r2.out = &tok2v;
   T tok2 = b.gemm(o2, b.wptr(t + ".attn2.to_out.0.weight"), C, C, b.vptr(t + ".attn2.to_out.0.bias"), r2);
   b.release(o2);
   b.release(tok1);
   // GEGLU feed-forward: LN3 + ff.net.0.proj + GEGLU in one launch (act 3: value * gelu(gate) in the GEMM epilogue, 4C columns out)
-  T gg = b.alloc(x.n, x.h, x.w, 4 * C);
+  T gg = compose ? ggv : b.alloc(x.n, x.h, x.w, 4 * C);
   {
     Builder::CO og; og.act = 3; og.out = &gg; og.ln = &st2; og.ln_s = b.named_v(t + ".ff1_ln.s");
     b.gemm(tok2, b.named_w(t + ".ff1_ln.w"), C, 8 * C, b.named_v(t + ".ff1_ln.b"), og);
   }
-  Builder::CO r3; r3.res = &tok2;
-  T tok3 = b.gemm(gg, b.wptr(t + ".ff.net.2.weight"), 4 * C, C, b.vptr(t + ".ff.net.2.bias"), r3);
-  b.release(gg);
-  b.release(tok2);
-  b.release_stats();
-  Builder::CO ro; ro.res = &x; ro.out = out; ro.gn_next = true;
-  T y = b.conv(tok3, p + ".proj_out", C, 1, 1, 0, ro);
-  b.release(tok3);
+  T y;
+  if (compose) {
+    b.release_stats();
+    Builder::CO ro; ro.res = &x; ro.out = out; ro.gn_next = true;
+    ro.w_ovr = b.named_w(t + ".ffproj.w"); ro.b_ovr = b.named_v(t + ".ffproj.b");
+    y = b.conv(cat, p + ".proj_out", C, 1, 1, 0, ro);
+    b.release(cat);
+  } else {
+    Builder::CO r3; r3.res = &tok2;
+    T tok3 = b.gemm(gg, b.wptr(t + ".ff.net.2.weight"), 4 * C, C, b.vptr(t + ".ff.net.2.bias"), r3);
+    b.release(gg);
+    b.release(tok2);
+    b.release_stats();
+    Builder::CO ro; ro.res = &x; ro.out = out; ro.gn_next = true;
+    y = b.conv(tok3, p + ".proj_out", C, 1, 1, 0, ro);
+    b.release(tok3);
+  }
   return y;
 }
 
@@ -1478,6 +1513,14 @@ int sdeo_finalize_weights(sdeo_handle h) {
     for (const FoldJob& f : h->folds)          // the row sums of the LayerNorm fold must be those of the re-quantised matrix
       if (int rc = row_sums_f16(reinterpret_cast<float*>(h->wslab + f.s_out), reinterpret_cast<const f16*>(h->wslab + f.w_out), f.rows, f.C, 0))
         return rc;
+  }
+  // ff.net.2 x proj_out products, from the values the fp16 copies hold NOW (the dequantised ones when weight_bits == 8)
+  for (const ComposeJob& cj : h->composes) {
+    auto off = [&](const std::string& n) { return h->wslab + h->weights[h->windex.at(n)].off; };
+    if (int rc = compose_proj(reinterpret_cast<f16*>(h->wslab + cj.w_out), reinterpret_cast<float*>(h->wslab + cj.b_out),
+                              reinterpret_cast<const f16*>(off(cj.wp)), reinterpret_cast<const float*>(off(cj.bp)),
+                              reinterpret_cast<const f16*>(off(cj.w2)), reinterpret_cast<const float*>(off(cj.b2)), cj.C, 4 * cj.C, 0))
+      return rc;
   }
   if (h->act_bits == 8) {
     // block-scaled packs of every Linear / conv1x1 matrix whose K is a multiple of 128 (from the values the fp16 copies hold now,
