@@ -77,7 +77,10 @@ __device__ __forceinline__ float xor32_sum(float v) {
 // pair own the same 32 queries and each takes one 32-key half of every staged tile, so the serial per-tile chain
 // (QK^T -> max -> exp -> PV) per wave halves and twice as many waves hide it; the two partial (m, l, O) states are merged
 // through LDS at the end.  Reduction order is fixed (half 0 then half 1), so results stay deterministic.
-template <int D16, int KS>
+// MPAD (head dims with a free K-dim slot, d % 16 == 8: d = 40): the softmax's per-score fma moves into the QK^T MFMA.  Q is scaled
+// by scale * log2 e once (fp16), the K tile's pad channel d holds 1, and Q's pad channel d holds -m, the row's running reference
+// (kept as an fp16-exact value), so the MFMA delivers  s * scale * log2 e - m  and the inner loop is max / exp / cvt only.
+template <int D16, int KS, bool MPAD>
 __global__ __launch_bounds__(256 * KS, (KS == 2 ? (D16 <= 4 ? 4 : 2) : (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))))
 void attention_kernel(const AP2 pp) {
   const AP& p = pp.k[blockIdx.y];      // blockIdx.y is always 0 (one problem per launch)
@@ -136,6 +139,13 @@ void attention_kernel(const AP2 pp) {
     }
   }
 
+  if constexpr (MPAD) {
+#pragma unroll
+    for (int ks = 0; ks < D16; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[ks][j] = (f16)((float)qf[ks][j] * sl2);
+  }
+
   const f16* kbase = p.k + (size_t)b * p.TkS * p.ldk + h * d;
   const f16* vbase = p.v + (size_t)b * p.TkSv * p.ldv + h * d;
   const int ntiles = (p.Tk + 63) / 64;
@@ -191,6 +201,7 @@ void attention_kernel(const AP2 pp) {
   for (int off = tid * 16; off < 2 * STAGE; off += NT * 16) *reinterpret_cast<f16x8*>(smem + off) = zero8;
   __syncthreads();
   if (ONES && tid < 128) *reinterpret_cast<f16*>(smem + (tid >> 6) * STAGE + KBYTES + (tid & 63) * VROW + R1 * 2) = (f16)1.f;
+  if (MPAD && tid < 128) *reinterpret_cast<f16*>(smem + (tid >> 6) * STAGE + (tid & 63) * KROW + d * 2) = (f16)1.f;   // K[key][d] = 1
 
   f32x16 o[DT];
 #pragma unroll
@@ -268,6 +279,40 @@ void attention_kernel(const AP2 pp) {
     for (int ki = 0; ki < NKB; ++ki)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[ki][r]);
+    float rs = 0.f;
+    if constexpr (MPAD) {
+      // the scores arrive as s * scale * log2 e - m_run (0 instead of m_run while the row has no reference yet)
+      mx = xor32_max(mx);
+      const bool unset = m_run == -INFINITY;
+      if (__any(mx > 8.0f || (unset && mx > -INFINITY))) {       // wave-uniform, rare (see the lazy rescale below)
+        const float m_abs = unset ? mx : m_run + fmaxf(mx, 0.f);  // the row's reference in absolute units: only ever raised
+        const float m_q = (float)(f16)m_abs;                       // ... as the fp16 value Q's pad channel can hold
+        const bool valid = m_abs > -INFINITY;                      // false: no visible key so far, the row stays unset
+        const float delta = valid ? m_q - (unset ? 0.f : m_run) : 0.f;
+        const float alpha = unset ? 0.f : __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int ki = 0; ki < NKB; ++ki)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[ki][r] -= delta;          // this tile was formed against the old reference
+        l_run *= alpha;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        if (valid) {
+          m_run = m_q;
+          if (lh == 1) qf[D16 - 1][0] = (f16)(-m_q);               // channel d of this row's Q: lanes lh = 1, last k-step, element 0
+        }
+      }
+#pragma unroll
+      for (int ki = 0; ki < NKB; ++ki)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(s[ki][r]);
+          s[ki][r] = pv;
+          if (!ONES) rs += pv;
+        }
+    } else {
     mx = xor32_max(mx) * sl2;
     // Lazy rescale: the running reference m_run moves only when some row's new maximum exceeds it by more than 8 (base-2 units),
     // i.e. P = 2^(s - m_run) stays below 2^8 -- exact in the fp32 accumulators and far inside fp16 for the P V operand.  The
@@ -286,7 +331,6 @@ void attention_kernel(const AP2 pp) {
     }
     // a key half that has not seen a single valid key yet (KS == 2, Tk <= 32) keeps m = -inf: exponentiate against 0
     const float m_use = (KS == 2 && m_run == -INFINITY) ? 0.f : m_run;
-    float rs = 0.f;
 #pragma unroll
     for (int ki = 0; ki < NKB; ++ki)
 #pragma unroll
@@ -295,6 +339,7 @@ void attention_kernel(const AP2 pp) {
         s[ki][r] = pv;
         if (!ONES) rs += pv;
       }
+    }
     if (!ONES) rs = xor32_sum(rs);
     l_run += rs;
 
@@ -594,7 +639,7 @@ static int launch_attn_wide(const AP& ap, int B, hipStream_t stream) {
   return 0;
 }
 
-template <int D16, int KS>
+template <int D16, int KS, bool MPAD>
 static int launch_attn_ks(const AP2& ap2, int count, int B, hipStream_t stream) {
   const AP& ap = ap2.k[0];
   constexpr int DT = (D16 + 1) / 2;
@@ -604,12 +649,12 @@ static int launch_attn_ks(const AP2& ap2, int count, int B, hipStream_t stream) 
   constexpr int smem = stage2 > merge ? stage2 : merge;
   static DeviceOnce attr_done;
   if (attr_done.need()) {
-    SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<D16, KS>),
+    SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<D16, KS, MPAD>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_done.mark();
   }
   dim3 grid(cdiv(ap.Tq, 128) * B * ap.H, count);
-  hipLaunchKernelGGL((attention_kernel<D16, KS>), grid, dim3(256 * KS), smem, stream, ap2);
+  hipLaunchKernelGGL((attention_kernel<D16, KS, MPAD>), grid, dim3(256 * KS), smem, stream, ap2);
   SDEO_HIP(hipGetLastError());
   return 0;
 }
@@ -625,9 +670,15 @@ static int attn_key_split(const AP& ap, int d16) {
 template <int D16>
 static int launch_attn(const AP2& ap, int count, int B, hipStream_t stream) {
   if constexpr (D16 <= 5) {
-    if (attn_key_split(ap.k[0], D16) == 2) return launch_attn_ks<D16, 2>(ap, count, B, stream);
+    // a free K-dim slot right after the head's channels (d = 8, 24, 40, 56, 72): the reference-in-the-pad form
+    static const bool mpad_on = [] { const char* e = getenv("SDEO_ATTN_MPAD"); return !e || atoi(e) != 0; }();
+    const bool mpad = mpad_on && ap.k[0].d % 16 == 8;
+    if (attn_key_split(ap.k[0], D16) == 2)
+      return mpad ? launch_attn_ks<D16, 2, true>(ap, count, B, stream) : launch_attn_ks<D16, 2, false>(ap, count, B, stream);
+    return mpad ? launch_attn_ks<D16, 1, true>(ap, count, B, stream) : launch_attn_ks<D16, 1, false>(ap, count, B, stream);
+  } else {
+    return launch_attn_ks<D16, 1, false>(ap, count, B, stream);
   }
-  return launch_attn_ks<D16, 1>(ap, count, B, stream);
 }
 
 static int attn_prepare(AP& ap, const AttnArgs& a) {
