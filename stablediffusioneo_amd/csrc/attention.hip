@@ -83,6 +83,7 @@ __device__ __forceinline__ float xor32_sum(float v) {
 template <int D16, int KS, bool MPAD>
 __global__ __launch_bounds__(256 * KS, (KS == 2 ? (D16 <= 4 ? 4 : 2) : (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))))
 void attention_kernel(const AP2 pp) {
+  kernarg_warm<sizeof(AP2)>();
   const AP& p = pp.k[blockIdx.y];      // blockIdx.y is always 0 (one problem per launch)
   constexpr int NT = 256 * KS;                               // threads per workgroup
   constexpr int NKB = 2 / KS;                                // 32-key blocks of a tile each wave handles

@@ -58,7 +58,15 @@ namespace sdeo {
 // 4x the K per MFMA at twice its cycles, half the operand bytes per FLOP.  GEMM (1x1) only, wave-specialised only.
 template <int BM, int BN, int STAGES, bool UPS, bool WS, bool W8 = false, int KPB = 1, bool MX = false>
 __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2 pp) {
-  const KP& p = pp.k[blockIdx.y];
+  kernarg_warm<sizeof(KP2)>();
+  // The scalars both roles need before their first DMA / fragment read, fetched in ONE batch and pinned in SGPRs: left to the
+  // compiler each is an s_load + s_waitcnt lgkmcnt(0) next to its first use, ten dependent scalar round trips in front of the
+  // first DMA of a launch whose whole K loop lasts a few microseconds.  (blockIdx.y is always 0: one problem per launch.)
+  KP pl = pp.k[0];
+  asm volatile("" : "+s"(pl.x), "+s"(pl.w), "+s"(pl.M), "+s"(pl.N), "+s"(pl.K), "+s"(pl.Hi), "+s"(pl.Wi), "+s"(pl.Cin), "+s"(pl.Wo),
+               "+s"(pl.S), "+s"(pl.stride), "+s"(pl.pad), "+s"(pl.HoWo), "+s"(pl.ldx), "+s"(pl.ldw), "+s"(pl.nk),
+               "+s"(pl.nk_per_split), "+s"(pl.tiles_m), "+s"(pl.tiles_n), "+s"(pl.n_fastest));
+  const KP& p = pl;
   static_assert(!MX || (WS && !W8 && !UPS && KPB == 1), "the block-scaled fp8 path exists for the plain wave-specialised GEMM");
   constexpr int BK = 64, RPP = 32;
   constexpr int WRPP = W8 ? 64 : 32;                           // weight rows per DMA pass
@@ -512,6 +520,7 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int BK, bool GENERIC>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const KP2 pp) {
+  kernarg_warm<sizeof(KP2)>();
   const KP& p = pp.k[blockIdx.y];
   constexpr int CPR = BK / 8;         // 16-byte chunks per tile row
   constexpr int RPP = 256 / CPR;      // tile rows covered per pass of the 256 threads
@@ -668,6 +677,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KP2 pp) {
 
 // split-K: sum the fp32 partial slabs and apply the epilogue. One thread per 4 output channels.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KP2 pp) {
+  kernarg_warm<sizeof(KP2)>();
   const KP& p = pp.k[blockIdx.y];
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int n4 = p.N / 4;

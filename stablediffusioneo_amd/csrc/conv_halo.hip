@@ -35,7 +35,12 @@ constexpr int halo_stages(int ph, int pw, int bn, int tpb = 1) {
 // third as often and the MFMA waves run three taps of fragment reads and MFMAs without meeting the loaders.
 template <int PH, int PW, int BN, int NMW, int TPB = 1>
 __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP2 pp) {
-  const KP& p = pp.k[blockIdx.y];
+  kernarg_warm<sizeof(KP2)>();
+  // prologue scalars in one batch, pinned in SGPRs (see conv_gemm_dma_kernel); blockIdx.y is always 0
+  KP pl = pp.k[0];
+  asm volatile("" : "+s"(pl.x), "+s"(pl.w), "+s"(pl.M), "+s"(pl.N), "+s"(pl.Hi), "+s"(pl.Wi), "+s"(pl.Cin), "+s"(pl.ldx), "+s"(pl.ldw),
+               "+s"(pl.nk_per_split), "+s"(pl.tiles_m), "+s"(pl.tiles_n), "+s"(pl.gn_in));
+  const KP& p = pl;
   constexpr int BM = PH * PW;
   constexpr int MI = BM / (16 * NMW), NI = BN / 16;
   constexpr int HWD = PW + 2, XREAL = (PH + 2) * HWD;

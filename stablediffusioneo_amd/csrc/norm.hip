@@ -43,6 +43,7 @@ static int gn_vec_per_block(int C, int groups) {
 // fixed 8-channel vector cv, so a wave reads whole contiguous NHWC rows.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnPair gp, int Bper, int HW, int C, int cpg, int nvb, int nchunks,
                                                        int groups, int ppc) {
+  kernarg_warm<sizeof(GnPair) + 24>();
   const GnOne& g1 = gp.k[0];
   const f16* __restrict__ x = g1.x;
   const int ldx = g1.ldx;
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnPair gp, int Bper
 // grid: (chunks, channel-parts, B): fold mean/rstd/gamma/beta into per-channel a,b in LDS, then y = x*a+b.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnPair gp, int Bper, int HW, int C, int cpg, int nvb,
                                                        int nchunks, int groups, float eps, int with_silu, int ppc, int nsc) {
+  kernarg_warm<sizeof(GnPair) + 24>();
   const GnOne& g1 = gp.k[0];
   f16* __restrict__ y = g1.y;
   const f16* __restrict__ x = g1.x;
@@ -281,6 +283,7 @@ int groupnorm_fold_partials(float* out, const float* in, int B, int nsc, int gro
 template <int NT>
 __global__ __launch_bounds__(NT) void gn_fused_kernel(const GnPair gp, int Bper, int HW, int cpg, int nvw, int nsweep, float eps,
                                                       int with_silu) {
+  kernarg_warm<sizeof(GnPair) + 24>();
   const GnOne& g1 = gp.k[0];
   f16* __restrict__ y = g1.y;
   const f16* __restrict__ x = g1.x;
