@@ -84,7 +84,12 @@ template <int D16, int KS, bool MPAD>
 __global__ __launch_bounds__(256 * KS, (KS == 2 ? (D16 <= 4 ? 4 : 2) : (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))))
 void attention_kernel(const AP2 pp) {
   kernarg_warm<sizeof(AP2)>();
-  const AP& p = pp.k[blockIdx.y];      // blockIdx.y is always 0 (one problem per launch)
+  // the whole parameter block in one batch, pinned in SGPRs (otherwise ~5 dependent s_load round trips before the first Q load);
+  // blockIdx.y is always 0 (one problem per launch)
+  AP pl = pp.k[0];
+  asm volatile("" : "+s"(pl.o), "+s"(pl.q), "+s"(pl.k), "+s"(pl.v), "+s"(pl.ldo), "+s"(pl.ldq), "+s"(pl.ldk), "+s"(pl.ldv), "+s"(pl.H),
+               "+s"(pl.Tq), "+s"(pl.Tk), "+s"(pl.TkS), "+s"(pl.TkSv), "+s"(pl.d), "+s"(pl.scale_log2), "+s"(pl.causal));
+  const AP& p = pl;
   constexpr int NT = 256 * KS;                               // threads per workgroup
   constexpr int NKB = 2 / KS;                                // 32-key blocks of a tile each wave handles
   constexpr int DT = (D16 + 1) / 2;                          // 32-row tiles of O^T

@@ -678,7 +678,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const KP2 pp) {
 // split-K: sum the fp32 partial slabs and apply the epilogue. One thread per 4 output channels.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KP2 pp) {
   kernarg_warm<sizeof(KP2)>();
-  const KP& p = pp.k[blockIdx.y];
+  // every scalar the loads below depend on, in one batch (see conv_gemm_dma_kernel); blockIdx.y is always 0
+  KP pl = pp.k[0];
+  asm volatile("" : "+s"(pl.y), "+s"(pl.bias), "+s"(pl.bias2), "+s"(pl.res), "+s"(pl.ws), "+s"(pl.M), "+s"(pl.N), "+s"(pl.HoWo),
+               "+s"(pl.ldy), "+s"(pl.ldres), "+s"(pl.ld_bias2), "+s"(pl.act), "+s"(pl.bias_per_row), "+s"(pl.splitk), "+s"(pl.ln_stats),
+               "+s"(pl.wscale), "+s"(pl.stats_out));
+  const KP& p = pl;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int n4 = p.N / 4;
   if (idx >= (int64_t)p.M * n4) return;
