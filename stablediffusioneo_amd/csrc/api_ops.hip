@@ -218,6 +218,11 @@ int sdeo_debug_fold_layernorm(void* w_out, float* s_out, float* b_out, const voi
   return fold_layernorm((f16*)w_out, s_out, b_out, (const f16*)w, gamma, beta, bias, rows, c, S(stream));
 }
 
+int sdeo_debug_compose_proj(void* w_out, float* b_out, const void* wp, const float* bp, const void* w2, const float* b2, int c, int k2,
+                            void* stream) {
+  return compose_proj((f16*)w_out, b_out, (const f16*)wp, bp, (const f16*)w2, b2, c, k2, S(stream));
+}
+
 int sdeo_debug_gemm_stats_f16(void* y, int ldy, const void* x, int ldx, const void* w, int ldw, const float* bias, const void* res,
                               int ldres, int m, int n, int k, float* stats, int stats_ld, int* strips_out, void* stream) {
   SDEO_CHECK(stats && strips_out, "gemm_stats: null argument");

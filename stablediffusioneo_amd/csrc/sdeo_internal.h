@@ -28,6 +28,9 @@ int sdeo_debug_silu(void* y, const void* x, int64_t n, void* stream);
  * row_stats: one (sum, sumsq) partial per row of x */
 int sdeo_debug_fold_layernorm(void* w_out, float* s_out, float* b_out, const void* w, const float* gamma, const float* beta,
                               const float* bias, int rows, int c, void* stream);
+/* [ (Wp W2) | Wp ] (fp16 [c][k2 + c]) and Wp b2 + bp (fp32 [c]): ff.net.2 and proj_out of a SpatialTransformer as one Linear */
+int sdeo_debug_compose_proj(void* w_out, float* b_out, const void* wp, const float* bp, const void* w2, const float* b2, int c, int k2,
+                            void* stream);
 int sdeo_debug_gemm_stats_f16(void* y, int ldy, const void* x, int ldx, const void* w, int ldw, const float* bias, const void* res,
                               int ldres, int m, int n, int k, float* stats, int stats_ld, int* strips_out, void* stream);
 int sdeo_debug_gemm_ln_f16(void* y, int ldy, const void* x, int ldx, const void* w_folded, int ldw, const float* ln_s,

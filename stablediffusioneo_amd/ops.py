@@ -189,6 +189,18 @@ def fold_layernorm(w, gamma, beta, bias=None):
     return wo, s, b
 
 
+def compose_proj(wp, bp, w2, b2):
+    """([ (wp w2) | wp ] as fp16 [c][k2 + c], wp b2 + bp fp32 [c]): ff.net.2 followed by proj_out as one Linear over [g | t]."""
+    lib = _lib.load()
+    _need_cuda(wp, bp, w2, b2)
+    c, k2 = w2.shape
+    assert wp.shape == (c, c) and wp.dtype == torch.float16 and w2.dtype == torch.float16 and wp.is_contiguous() and w2.is_contiguous()
+    wo = torch.empty((c, k2 + c), dtype=torch.float16, device=wp.device)
+    bo = torch.empty((c,), dtype=torch.float32, device=wp.device)
+    check(lib.sdeo_debug_compose_proj(ptr(wo), ptr(bo), ptr(wp), ptr(bp), ptr(w2), ptr(b2), _i(c), _i(k2), cur_stream()), "compose_proj")
+    return wo, bo
+
+
 def gemm_with_row_stats(x, w, bias=None, res=None):
     """y = x w^T (+bias)(+res) in fp16 plus the per-row (sum, sumsq) partials its epilogue writes: (y, stats [m][ld][2], strips).
     When the plan for this shape is split-K the statistics come from the row_stats kernel (strips = 1), as in the networks."""

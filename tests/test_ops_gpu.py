@@ -366,6 +366,29 @@ def test_gemm_with_folded_layernorm(ops, case):
     assert_close(y, ref, rtol=4e-3, atol=4e-3, what=f"LayerNorm-folded GEMM {case}")
 
 
+@pytest.mark.parametrize("case", [(256, 64), (512, 320), (96, 640)], ids=str)
+def test_composed_ff2_proj_out(ops, case):
+    """ff.net.2 followed by the SpatialTransformer's proj_out (`attention.py:75-76`, `:385`, `:431-450`) as ONE Linear over the
+    row-concatenated operand [g | t] (stablediffusioneo_amd/csrc/net.hip: ComposeJob, built at weight finalisation):
+    proj_out(ff2(g) + t) + x  ==  [g | t] [ (Wp W2) | Wp ]^T + (Wp b2 + bp) + x.  Reference: the two Linear maps in fp32."""
+    rows, c = case
+    k2 = 4 * c
+    w2 = h16(randn((c, k2), 810) * k2 ** -0.5).to(DEV)
+    b2 = (0.1 * randn((c,), 811)).to(DEV)
+    wp = h16(randn((c, c), 812) * c ** -0.5).to(DEV)
+    bp = (0.1 * randn((c,), 813)).to(DEV)
+    wc, bc = ops.compose_proj(wp, bp, w2, b2)
+    assert_close(wc[:, :k2], wp.float() @ w2.float(), rtol=2e-3, atol=2e-3, what=f"Wp W2 {case}")
+    assert torch.equal(wc[:, k2:], wp)
+    assert_close(bc, wp.float() @ b2 + bp, rtol=1e-4, atol=1e-4, what=f"composed bias {case}")
+    cat = h16(randn((rows, k2 + c), 814)).to(DEV)          # [GEGLU output | tok2], one buffer as the network lays it out
+    x = h16(randn((rows, c), 815)).to(DEV)
+    y = ops.gemm(cat, wc, bias=bc, res=x)
+    g, t = cat[:, :k2].float(), cat[:, k2:].float()
+    ref = F.linear(F.linear(g, w2.float(), b2) + t, wp.float(), bp) + x.float()
+    assert_close(y, ref, rtol=4e-3, atol=4e-3, what=f"composed ff.net.2 + proj_out {case}")
+
+
 def test_timestep_embedding(ops):
     g = np.load(os.path.join(GOLDEN, "blocks.npz"))
     t = torch.tensor([1, 51, 501, 951, 981], dtype=torch.long)
