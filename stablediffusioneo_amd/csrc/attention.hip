@@ -87,7 +87,8 @@ void attention_kernel(const AP2 pp) {
   // the whole parameter block in one batch, pinned in SGPRs (otherwise ~5 dependent s_load round trips before the first Q load);
   // blockIdx.y is always 0 (one problem per launch)
   AP pl = pp.k[0];
-  asm volatile("" : "+s"(pl.o), "+s"(pl.q), "+s"(pl.k), "+s"(pl.v), "+s"(pl.ldo), "+s"(pl.ldq), "+s"(pl.ldk), "+s"(pl.ldv), "+s"(pl.H),
+  // (integers / floats only: a pointer that has been through the asm loses its address space and its accesses become flat_ ones)
+  asm volatile("" : "+s"(pl.ldo), "+s"(pl.ldq), "+s"(pl.ldk), "+s"(pl.ldv), "+s"(pl.H),
                "+s"(pl.Tq), "+s"(pl.Tk), "+s"(pl.TkS), "+s"(pl.TkSv), "+s"(pl.d), "+s"(pl.scale_log2), "+s"(pl.causal));
   const AP& p = pl;
   constexpr int NT = 256 * KS;                               // threads per workgroup
@@ -137,19 +138,13 @@ void attention_kernel(const AP2 pp) {
   f16x8 qf[D16];
   {
     const f16* qp = p.q + ((size_t)b * p.Tq + (qvalid ? qrow : 0)) * p.ldq + h * d;
+    // unconditional loads (rows past Tq read row 0, chunks past d read chunk 0; zeroed at their first use below): a load under an
+    // exec mask cannot be counted by the compiler's wait pass, and every later wait of the prologue would become vmcnt(0)
 #pragma unroll
     for (int ks = 0; ks < D16; ++ks) {
       const int c = (ks * 2 + lh) * 8;
-      if (qvalid && c < d) qf[ks] = *reinterpret_cast<const f16x8*>(qp + c);
-      else qf[ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      qf[ks] = *reinterpret_cast<const f16x8*>(qp + (c < d ? c : 0));
     }
-  }
-
-  if constexpr (MPAD) {
-#pragma unroll
-    for (int ks = 0; ks < D16; ++ks)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) qf[ks][j] = (f16)((float)qf[ks][j] * sl2);
   }
 
   const f16* kbase = p.k + (size_t)b * p.TkS * p.ldk + h * d;
@@ -203,6 +198,10 @@ void attention_kernel(const AP2 pp) {
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
+  // Prologue order: EVERY global load of the prologue (Q above, tile 0, tile 1) is in flight before the LDS is initialised, so the
+  // zero fill and its barrier pass under one memory round trip instead of standing between two of them.
+  load_tile(S0{}, 0);
+  if constexpr (DEEP) load_tile(S1{}, 1);           // set 1 carries the odd tiles, set 0 the even ones
   // both stages start as zeros (+ the ones column of V): staging only ever writes the chunk slots below d
   for (int off = tid * 16; off < 2 * STAGE; off += NT * 16) *reinterpret_cast<f16x8*>(smem + off) = zero8;
   __syncthreads();
@@ -216,17 +215,20 @@ void attention_kernel(const AP2 pp) {
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  load_tile(S0{}, 0);
-  store_tile(S0{}, 0);
-  // a use of the Q fragments HERE, before the prefetch loads are issued: their wait is then placed in front of the loop.  Left
-  // to its first real use (the first MFMA of the loop) the compiler must assume Q still in flight on every iteration and waits
-  // vmcnt(0) at the top of each tile, which serialises the prefetched K / V loads with the compute they were meant to hide behind.
+  // the first real use of the Q fragments HERE (MPAD: scaled by scale * log2 e), before the later prefetch loads are issued: their
+  // wait is then placed in front of the loop.  Left to the first MFMA of the loop the compiler must assume Q still in flight on
+  // every iteration and waits vmcnt(0) at the top of each tile, which serialises the prefetched K / V loads with the compute they
+  // were meant to hide behind.
 #pragma unroll
-  for (int ks = 0; ks < D16; ++ks) asm volatile("" ::"v"(qf[ks]));
-  if constexpr (DEEP) {
-    load_tile(S1{}, 1);                             // set 1 carries the odd tiles, set 0 the even ones
-    load_tile(S0{}, 2);
+  for (int ks = 0; ks < D16; ++ks) {
+    const bool live = qvalid && (ks * 2 + lh) * 8 < d;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qf[ks][j] = live ? (MPAD ? (f16)((float)qf[ks][j] * sl2) : qf[ks][j]) : (f16)0.f;
   }
+#pragma unroll
+  for (int ks = 0; ks < D16; ++ks) asm volatile("" : "+v"(qf[ks]));
+  store_tile(S0{}, 0);
+  if constexpr (DEEP) load_tile(S0{}, 2);
   __syncthreads();
 
   // one 64-key tile; at its end the NEXT tile (loaded two iterations ago) goes from registers to the other LDS buffer and the

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(WS ? 512 : 256) void conv_gemm_dma_kernel(const KP2
   // compiler each is an s_load + s_waitcnt lgkmcnt(0) next to its first use, ten dependent scalar round trips in front of the
   // first DMA of a launch whose whole K loop lasts a few microseconds.  (blockIdx.y is always 0: one problem per launch.)
   KP pl = pp.k[0];
-  asm volatile("" : "+s"(pl.x), "+s"(pl.w), "+s"(pl.M), "+s"(pl.N), "+s"(pl.K), "+s"(pl.Hi), "+s"(pl.Wi), "+s"(pl.Cin), "+s"(pl.Wo),
+  // (integers only: a pointer that has been through the asm loses its address space and every access through it becomes a flat_ one)
+  asm volatile("" : "+s"(pl.M), "+s"(pl.N), "+s"(pl.K), "+s"(pl.Hi), "+s"(pl.Wi), "+s"(pl.Cin), "+s"(pl.Wo),
                "+s"(pl.S), "+s"(pl.stride), "+s"(pl.pad), "+s"(pl.HoWo), "+s"(pl.ldx), "+s"(pl.ldw), "+s"(pl.nk),
                "+s"(pl.nk_per_split), "+s"(pl.tiles_m), "+s"(pl.tiles_n), "+s"(pl.n_fastest));
   const KP& p = pl;
@@ -680,9 +681,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KP2 pp) {
   kernarg_warm<sizeof(KP2)>();
   // every scalar the loads below depend on, in one batch (see conv_gemm_dma_kernel); blockIdx.y is always 0
   KP pl = pp.k[0];
-  asm volatile("" : "+s"(pl.y), "+s"(pl.bias), "+s"(pl.bias2), "+s"(pl.res), "+s"(pl.ws), "+s"(pl.M), "+s"(pl.N), "+s"(pl.HoWo),
-               "+s"(pl.ldy), "+s"(pl.ldres), "+s"(pl.ld_bias2), "+s"(pl.act), "+s"(pl.bias_per_row), "+s"(pl.splitk), "+s"(pl.ln_stats),
-               "+s"(pl.wscale), "+s"(pl.stats_out));
+  asm volatile("" : "+s"(pl.M), "+s"(pl.N), "+s"(pl.HoWo), "+s"(pl.ldy), "+s"(pl.ldres), "+s"(pl.ld_bias2), "+s"(pl.act),
+               "+s"(pl.bias_per_row), "+s"(pl.splitk));     // integers only: pinned pointers would turn their accesses into flat_ ones
   const KP& p = pl;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int n4 = p.N / 4;

@@ -38,8 +38,9 @@ __global__ __launch_bounds__(NMW * 64 + 256) void conv3x3_halo_kernel(const KP2 
   kernarg_warm<sizeof(KP2)>();
   // prologue scalars in one batch, pinned in SGPRs (see conv_gemm_dma_kernel); blockIdx.y is always 0
   KP pl = pp.k[0];
-  asm volatile("" : "+s"(pl.x), "+s"(pl.w), "+s"(pl.M), "+s"(pl.N), "+s"(pl.Hi), "+s"(pl.Wi), "+s"(pl.Cin), "+s"(pl.ldx), "+s"(pl.ldw),
-               "+s"(pl.nk_per_split), "+s"(pl.tiles_m), "+s"(pl.tiles_n), "+s"(pl.gn_in));
+  // (integers only: a pointer that has been through the asm loses its address space and every access through it becomes a flat_ one)
+  asm volatile("" : "+s"(pl.M), "+s"(pl.N), "+s"(pl.Hi), "+s"(pl.Wi), "+s"(pl.Cin), "+s"(pl.ldx), "+s"(pl.ldw),
+               "+s"(pl.nk_per_split), "+s"(pl.tiles_m), "+s"(pl.tiles_n));
   const KP& p = pl;
   constexpr int BM = PH * PW;
   constexpr int MI = BM / (16 * NMW), NI = BN / 16;
