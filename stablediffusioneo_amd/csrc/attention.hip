@@ -80,8 +80,10 @@ __device__ __forceinline__ float xor32_sum(float v) {
 // MPAD (head dims with a free K-dim slot, d % 16 == 8: d = 40): the softmax's per-score fma moves into the QK^T MFMA.  Q is scaled
 // by scale * log2 e once (fp16), the K tile's pad channel d holds 1, and Q's pad channel d holds -m, the row's running reference
 // (kept as an fp16-exact value), so the MFMA delivers  s * scale * log2 e - m  and the inner loop is max / exp / cvt only.
-template <int D16, int KS, bool MPAD>
-__global__ __launch_bounds__(256 * KS, (KS == 2 ? (D16 <= 4 ? 4 : 2) : (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))))
+// QB: 32-query blocks per workgroup (4: 128 queries; 2: 64 queries, twice the workgroups, each staging the K / V tiles for half as
+// many queries but with only QB * KS waves behind one barrier).
+template <int D16, int KS, bool MPAD, int QB = 4>
+__global__ __launch_bounds__(64 * QB * KS, (KS == 2 ? (D16 <= 4 ? 4 : 2) : (D16 <= 2 ? 4 : (D16 <= 5 ? 2 : 1))))
 void attention_kernel(const AP2 pp) {
   kernarg_warm<sizeof(AP2)>();
   // the whole parameter block in one batch, pinned in SGPRs (otherwise ~5 dependent s_load round trips before the first Q load);
@@ -91,7 +93,7 @@ void attention_kernel(const AP2 pp) {
   asm volatile("" : "+s"(pl.ldo), "+s"(pl.ldq), "+s"(pl.ldk), "+s"(pl.ldv), "+s"(pl.H),
                "+s"(pl.Tq), "+s"(pl.Tk), "+s"(pl.TkS), "+s"(pl.TkSv), "+s"(pl.d), "+s"(pl.scale_log2), "+s"(pl.causal));
   const AP& p = pl;
-  constexpr int NT = 256 * KS;                               // threads per workgroup
+  constexpr int NT = 64 * QB * KS;                           // threads per workgroup
   constexpr int NKB = 2 / KS;                                // 32-key blocks of a tile each wave handles
   constexpr int DT = (D16 + 1) / 2;                          // 32-row tiles of O^T
   constexpr int KROW = D16 * 32 + ((D16 * 2) % 2 == 0 ? 16 : 0);  // K tile row bytes (odd multiple of 16)
@@ -115,7 +117,7 @@ void attention_kernel(const AP2 pp) {
   const int kh = KS == 2 ? (wave & 1) : 0;                   // key half of this wave (KS == 2)
   // XCD-aware placement (speed only): workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous
   // run of (batch, head) pairs so the K / V^T of a head stay in ONE private L2 instead of being streamed by all eight
-  const int qtiles = (p.Tq + 127) >> 7;
+  const int qtiles = (p.Tq + 32 * QB - 1) / (32 * QB);
   int wg = blockIdx.x, nwg = gridDim.x;
   {
     const int q_ = nwg >> 3, r_ = nwg & 7, xcd = wg & 7, idx = wg >> 3;
@@ -123,7 +125,7 @@ void attention_kernel(const AP2 pp) {
   }
   const int bh = wg / qtiles;
   const int b = bh / p.H, h = bh - b * p.H;
-  const int q0 = (wg - bh * qtiles) * 128 + qb * 32;
+  const int q0 = (wg - bh * qtiles) * (32 * QB) + qb * 32;
   const int qrow = q0 + lq;
   const bool qvalid = qrow < p.Tq;
   const int d = p.d;
@@ -158,7 +160,7 @@ void attention_kernel(const AP2 pp) {
   // Every load is UNCONDITIONAL (rows past Tk read row Tk - 1 again: those keys are masked to -inf, so P is 0 against a finite
   // V; threads without a chunk read chunk 0 and never store): with loads under exec masks or uniform branches the compiler
   // cannot count them and turns every wait into vmcnt(0), which serialises the prefetch with the compute it should hide behind.
-  constexpr bool DEEP = D16 <= 5;
+  constexpr bool DEEP = D16 <= 5 && QB == 4;      // 64-query workgroups: one set (two passes per thread already fill the registers)
   f16x8 kr[DEEP ? 2 : 1][KPASS], vr[DEEP ? 2 : 1][KPASS];
   int krow[KPASS], kcol[KPASS], kdst[KPASS], vdst[KPASS];
 #pragma unroll
@@ -647,22 +649,22 @@ static int launch_attn_wide(const AP& ap, int B, hipStream_t stream) {
   return 0;
 }
 
-template <int D16, int KS, bool MPAD>
+template <int D16, int KS, bool MPAD, int QB = 4>
 static int launch_attn_ks(const AP2& ap2, int count, int B, hipStream_t stream) {
   const AP& ap = ap2.k[0];
   constexpr int DT = (D16 + 1) / 2;
   constexpr int KROW = D16 * 32 + ((D16 * 2) % 2 == 0 ? 16 : 0);
   constexpr int stage2 = 2 * (64 * KROW + 64 * attn_vrow(DT));
-  constexpr int merge = KS == 2 ? 4 * (2 + DT * 16) * 64 * 4 : 0;     // LDS of the key-half merge
+  constexpr int merge = KS == 2 ? QB * (2 + DT * 16) * 64 * 4 : 0;    // LDS of the key-half merge
   constexpr int smem = stage2 > merge ? stage2 : merge;
   static DeviceOnce attr_done;
   if (attr_done.need()) {
-    SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<D16, KS, MPAD>),
+    SDEO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<D16, KS, MPAD, QB>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_done.mark();
   }
-  dim3 grid(cdiv(ap.Tq, 128) * B * ap.H, count);
-  hipLaunchKernelGGL((attention_kernel<D16, KS, MPAD>), grid, dim3(256 * KS), smem, stream, ap2);
+  dim3 grid(cdiv(ap.Tq, 32 * QB) * B * ap.H, count);
+  hipLaunchKernelGGL((attention_kernel<D16, KS, MPAD, QB>), grid, dim3(64 * QB * KS), smem, stream, ap2);
   SDEO_HIP(hipGetLastError());
   return 0;
 }
@@ -681,8 +683,18 @@ static int launch_attn(const AP2& ap, int count, int B, hipStream_t stream) {
     // a free K-dim slot right after the head's channels (d = 8, 24, 40, 56, 72): the reference-in-the-pad form
     static const bool mpad_on = [] { const char* e = getenv("SDEO_ATTN_MPAD"); return !e || atoi(e) != 0; }();
     const bool mpad = mpad_on && ap.k[0].d % 16 == 8;
-    if (attn_key_split(ap.k[0], D16) == 2)
+    if (attn_key_split(ap.k[0], D16) == 2) {
+      if constexpr (D16 == 3 || D16 == 5) {
+        // 64-query workgroups where 128-query ones leave CUs empty (T = 1024 on 16 (batch, head) pairs: 128 workgroups on 256 CUs;
+        // measured 19.3 -> 17.2 us at d = 80); with the chip already full they lose (T = 4096: 71 -> 95 us: twice the staging per
+        // query, one prefetch set).  SDEO_ATTN_QB = 2 / 4 forces one form (measurement).  Instantiated for d = 40 / 80.
+        static const int qb_forced = [] { const char* e = getenv("SDEO_ATTN_QB"); return e ? atoi(e) : 0; }();
+        const bool small_grid = cdiv(ap.k[0].Tq, 128) * B * ap.k[0].H < 256;
+        if (qb_forced ? qb_forced == 2 : small_grid)
+          return mpad ? launch_attn_ks<D16, 2, true, 2>(ap, count, B, stream) : launch_attn_ks<D16, 2, false, 2>(ap, count, B, stream);
+      }
       return mpad ? launch_attn_ks<D16, 2, true>(ap, count, B, stream) : launch_attn_ks<D16, 2, false>(ap, count, B, stream);
+    }
     return mpad ? launch_attn_ks<D16, 1, true>(ap, count, B, stream) : launch_attn_ks<D16, 1, false>(ap, count, B, stream);
   } else {
     return launch_attn_ks<D16, 1, false>(ap, count, B, stream);
