@@ -784,7 +784,9 @@ struct Builder {
   // conv3x3(act(GroupNorm(x))) (`openaimodel.py:255-275`, `model.py:129-149`).  When x carries its producer's partials and the conv's
   // plan is a halo-reuse kernel with LDS left for the (a, b) table, the conv applies the GroupNorm itself (KP::gn_in): no GroupNorm
   // launch, no normalised copy.  Otherwise GroupNorm launch(es) + conv.
-  static bool gn_in_enabled() { static const bool on = [] { const char* v = getenv("SDEO_GN_IN_CONV"); return !v || atoi(v) != 0; }(); return on; }
+  // default OFF since the end of round 3: with the launch prologues shortened (kernel-argument fetch) the 21 GroupNorm launches it
+  // removes cost less than the ~6 us it adds to each conv (three same-box alternations: 5.931 vs 5.876 ms per step, 8.13 vs 8.22 images/s)
+  static bool gn_in_enabled() { static const bool on = [] { const char* v = getenv("SDEO_GN_IN_CONV"); return v && atoi(v) != 0; }(); return on; }
   T gn_conv(const T& x, const std::string& gn_name, float eps, int silu_, const std::string& conv_name, int cout, CO o) {
     if (gn_in_enabled() && !e->autotune && x.gnp && x.gn_slots > 0 && x.c % 32 == 0) {
       ConvGemm q;

@@ -141,3 +141,18 @@ def test_full_sd15_latent8_vs_reference_golden(full):
     for i, c in enumerate(ctrl):
         check(c, g[f"control{i}"], f"sd15 control{i}")
     check(rt.apply_model(x, hint, t, ctx), g["eps"], "sd15 eps (apply_model)")
+
+
+def test_optional_schedules_keep_parity():
+    """The schedule variants that are off by default -- GroupNorm applied inside the consuming conv (SDEO_GN_IN_CONV=1), ff.net.2 and
+    proj_out as two launches (SDEO_COMPOSE_FF=0) -- read their switch once per process, so the golden comparisons of this file and
+    one full-size pass run again in ONE child process with both flipped."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SDEO_GN_IN_CONV="1", SDEO_COMPOSE_FF="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_nets_gpu.py"), os.path.join(root, "tests", "test_fullsize_golden_gpu.py"),
+                        "-k", "(golden or vae_decode or pass64) and not optional_schedules"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
