@@ -131,6 +131,10 @@ int sdeo_resize_lanczos4_u8(uint8_t* dst, const uint8_t* src, int h, int w, int 
 int sdeo_resize_area_u8(uint8_t* dst, const uint8_t* src, int h, int w, int c, int dst_h, int dst_w, const int32_t* x_start,
                         const int32_t* x_index, const float* x_weight, const int32_t* y_start, const int32_t* y_index,
                         const float* y_weight, void* stream);
+/* INTER_AREA when both axes shrink by INTEGER factors (h % dst_h == 0, w % dst_w == 0; error otherwise): OpenCV's resizeAreaFast_
+ * arithmetic -- 2 x 2 cells (a + b + c + d + 2) >> 2, other cells the integer cell sum times the float 1 / area, ties to even.  No
+ * tables.  (cv2.resize picks this path by itself; stablediffusioneo_amd/annotator/util.py: resize_u8 does the same.) */
+int sdeo_resize_area_fast_u8(uint8_t* dst, const uint8_t* src, int h, int w, int c, int dst_h, int dst_w, void* stream);
 
 /* layout helpers at the NCHW boundary */
 int sdeo_nchw_f32_to_nhwc_f16(void* y, int ldy, const float* x, int n, int c, int hw, void* stream);

@@ -73,9 +73,8 @@ def _area_axis(ssize: int, dsize: int):
 
     Known deviations from cv2 (cv2 is not installed in this image, so INTER_AREA is "parity unpinned"; the Lanczos path, the one
     `process()` takes for the benchmark sizes, is the integer-exact one):
-      * both axes shrinking by the SAME INTEGER factor: cv2 takes `resizeAreaFast_` (integer sum of the scale x scale cell, then
-        `saturate_cast<uchar>((sum + area/2) / area)` style rounding for u8); here the cell is averaged in fp32 with weights 1/area
-        and rounded to nearest even -- results can differ by 1 code on exact .5 ties;
+      * (both axes shrinking by integer factors do not come here: `resize_u8` takes cv2's `resizeAreaFast_` arithmetic,
+        `sdeo_resize_area_fast_u8`)
       * an axis that GROWS under INTER_AREA: cv2 runs its u8 bilinear kernel in 11-bit fixed point (weights x 2048, two rounding
         shifts); here the linear pair is applied in fp32 -- differences of at most 1 code."""
     scale = np.float64(ssize) / np.float64(dsize)
@@ -132,6 +131,9 @@ def resize_u8(img, dst_h: int, dst_w: int, interpolation: str):
         y0, by = _lanczos4_axis(h, dst_h)
         tabs = [dev(a) for a in (x0, ax, y0, by)]
         check(lib.sdeo_resize_lanczos4_u8(ptr(out), ptr(t), *geo, *[ptr(a) for a in tabs], cur_stream()), "resize_lanczos4")
+    elif interpolation == "area" and h % dst_h == 0 and w % dst_w == 0:
+        # both axes shrink by integer factors: cv2 switches to resizeAreaFast_ (integer cell sums), so does this
+        check(lib.sdeo_resize_area_fast_u8(ptr(out), ptr(t), *geo, cur_stream()), "resize_area_fast")
     elif interpolation == "area":
         tabs = [dev(a) for a in (*_area_axis(w, dst_w), *_area_axis(h, dst_h))]
         check(lib.sdeo_resize_area_u8(ptr(out), ptr(t), *geo, *[ptr(a) for a in tabs], cur_stream()), "resize_area")

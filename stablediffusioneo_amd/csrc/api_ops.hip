@@ -104,6 +104,10 @@ int sdeo_resize_area_u8(uint8_t* dst, const uint8_t* src, int h, int w, int c, i
   return resize_area_u8(dst, src, h, w, c, dst_h, dst_w, x_start, x_index, x_weight, y_start, y_index, y_weight, S(stream));
 }
 
+int sdeo_resize_area_fast_u8(uint8_t* dst, const uint8_t* src, int h, int w, int c, int dst_h, int dst_w, void* stream) {
+  return resize_area_fast_u8(dst, src, h, w, c, dst_h, dst_w, S(stream));
+}
+
 int sdeo_debug_read_stamps(int which, unsigned long long* out, int n) {
   return which ? conv_halo_read_stamps(out, n) : conv_gemm_read_stamps(out, n);
 }

@@ -190,6 +190,7 @@ int resize_lanczos4_u8(uint8_t* dst, const uint8_t* src, int h, int w, int c, in
                        const int* y0, const short* by, hipStream_t stream);
 int resize_area_u8(uint8_t* dst, const uint8_t* src, int h, int w, int c, int dh, int dw, const int* xstart, const int* xidx,
                    const float* xw, const int* ystart, const int* yidx, const float* yw, hipStream_t stream);
+int resize_area_fast_u8(uint8_t* dst, const uint8_t* src, int h, int w, int c, int dh, int dw, hipStream_t stream);
 // classifier-free guidance + DDIM update on NCHW fp32 latents (ddim_hacked.py:192,208-231)
 int cfg_ddim_pair(float* x, float* pred_x0, const f16* eps, int lde, f16* x0, int ld0, int b, int C, int HW, float cfg_scale, float a_t,
                   float a_prev, float sqrt_one_minus_at, hipStream_t stream);

@@ -65,6 +65,33 @@ __global__ __launch_bounds__(256) void resize_area_kernel(uint8_t* __restrict__ 
   }
 }
 
+// INTER_AREA when BOTH axes shrink by integer factors (sy = h / dh, sx = w / dw): OpenCV leaves `resizeArea_` for `resizeAreaFast_`
+// (resize.cpp: `is_area_fast`), which is integer arithmetic -- restated here, parity unpinned like the rest of this file (no cv2 in
+// the image):  2 x 2 cells of 8-bit images: (a + b + c + d + 2) >> 2 (`ResizeAreaFastVec`, round half UP);  any other cell: the
+// integer sum of the sy x sx cell times the float 1 / (sx * sy), cvRound (ties to even), saturate (`ResizeAreaFast_Invoker`).
+__global__ __launch_bounds__(256) void resize_area_fast_kernel(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, int w, int c,
+                                                               int dh, int dw, int sy, int sx) {
+  const int64_t total = (int64_t)dh * dw * c;
+  const float scale = 1.f / (float)(sx * sy);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    const int dx = (int)((i / c) % dw);
+    const int dy = (int)(i / ((int64_t)c * dw));
+    const uint8_t* cell = src + ((size_t)dy * sy * w + (size_t)dx * sx) * c + ch;
+    int sum = 0;
+    for (int y = 0; y < sy; ++y)
+      for (int x = 0; x < sx; ++x) sum += (int)cell[((size_t)y * w + x) * c];
+    int v;
+    if (sx == 2 && sy == 2) {
+      v = (sum + 2) >> 2;
+    } else {
+      const float r = rintf((float)sum * scale);
+      v = (int)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+    }
+    dst[i] = (uint8_t)v;
+  }
+}
+
 static inline dim3 resize_grid(int64_t n) {
   int64_t b = cdiv64(n, 256);
   return dim3((unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b)));
@@ -85,6 +112,15 @@ int resize_area_u8(uint8_t* dst, const uint8_t* src, int h, int w, int c, int dh
   SDEO_CHECK(h > 0 && w > 0 && c >= 1 && c <= 4 && dh > 0 && dw > 0, "resize_area: bad geometry %dx%dx%d -> %dx%d", h, w, c, dh, dw);
   hipLaunchKernelGGL(resize_area_kernel, resize_grid((int64_t)dh * dw * c), dim3(256), 0, stream, dst, src, w, c, dh, dw, xstart, xidx, xw,
                      ystart, yidx, yw);
+  SDEO_HIP(hipGetLastError());
+  return 0;
+}
+
+int resize_area_fast_u8(uint8_t* dst, const uint8_t* src, int h, int w, int c, int dh, int dw, hipStream_t stream) {
+  SDEO_CHECK(dst && src, "resize_area_fast: null operand");
+  SDEO_CHECK(h > 0 && w > 0 && c >= 1 && c <= 4 && dh > 0 && dw > 0 && h % dh == 0 && w % dw == 0,
+             "resize_area_fast: %dx%dx%d -> %dx%d is not a shrink by integer factors", h, w, c, dh, dw);
+  hipLaunchKernelGGL(resize_area_fast_kernel, resize_grid((int64_t)dh * dw * c), dim3(256), 0, stream, dst, src, w, c, dh, dw, h / dh, w / dw);
   SDEO_HIP(hipGetLastError());
   return 0;
 }

@@ -27,6 +27,18 @@ def test_resize_image_bit_exact(shape, res):
     assert t.is_cuda and np.array_equal(t.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("shape,dst", [((512, 640, 3), (256, 320)), ((96, 120, 3), (24, 40)), ((64, 64, 1), (16, 64)), ((30, 42, 4), (10, 6))])
+def test_area_integer_factors_take_the_fast_path(shape, dst):
+    """both axes shrink by integer factors (2 x 2: the reference's own bag_scribble.png case, 512 x 640 at resolution 256; 4 x 3; 4 x 1;
+    3 x 7): `sdeo_resize_area_fast_u8` bit-exact against the oracle's restatement of OpenCV's resizeAreaFast_"""
+    from oracle import resize_oracle as R
+    from stablediffusioneo_amd.annotator.util import resize_u8
+    img = rnd(*shape, seed=shape[1])
+    want = R.resize_area_fast(img, *dst)
+    assert np.array_equal(R.cv2_resize(img, (dst[1], dst[0]), "area"), want)
+    assert np.array_equal(resize_u8(img, dst[0], dst[1], "area"), want)
+
+
 def test_resize_extremes():
     from oracle import resize_oracle as R
     from stablediffusioneo_amd.annotator.util import resize_u8

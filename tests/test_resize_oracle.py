@@ -28,6 +28,20 @@ def test_area_integer_factor_is_the_block_mean():
     assert np.abs(out3.astype(np.float64) - mean3).max() <= 0.5 + 1e-4
 
 
+def test_area_fast_path_arithmetic():
+    """Both axes shrinking by integer factors: OpenCV's `resizeAreaFast_` arithmetic (known answers worked by hand).
+    2 x 2: (a + b + c + d + 2) >> 2, i.e. ties round UP (sum 10 -> 3, where round-half-even of 2.5 would give 2); other cells:
+    int sum * float32(1 / area), ties to even (a 2 x 1 cell with sum 5 -> 2, with sum 7 -> 4)."""
+    img = np.array([[[1], [2], [0], [0]], [[3], [4], [1], [1]]], dtype=np.uint8)         # cells: sum 10 -> 3, sum 2 -> 1
+    assert R.cv2_resize(img, (2, 1), "area").ravel().tolist() == [3, 1]
+    col = np.array([[[2]], [[3]], [[3]], [[4]]], dtype=np.uint8)                           # 2 x 1 cells: sums 5 and 7
+    assert R.cv2_resize(col, (1, 2), "area").ravel().tolist() == [2, 4]
+    big = rnd(48, 60, 3, 5)
+    out = R.cv2_resize(big, (20, 12), "area")                                              # 4 x 3 cells
+    cells = big.astype(np.int64).reshape(12, 4, 20, 3, 3).sum((1, 3))
+    assert np.array_equal(out, np.rint(cells.astype(np.float32) * (np.float32(1.0) / np.float32(12.0))).astype(np.uint8))
+
+
 def test_area_fractional_weights_sum_to_one_and_cover_the_cell():
     for s, d in ((100, 64), (333, 128), (97, 96), (1000, 7)):
         for ent in R.area_tab(s, d):
