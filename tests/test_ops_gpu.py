@@ -467,6 +467,37 @@ def test_attention_spike(ops):
     assert_close(o, ref, rtol=3e-3, atol=3e-3, what="attention spike")
 
 
+@pytest.mark.parametrize("d,amp", [(40, 30.0), (40, 6.0), (80, 30.0), (8, 20.0)], ids=str)
+def test_attention_large_scores(ops, d, amp):
+    """scores of magnitude ~10^3 (base-2 units): the softmax reference is then tracked in coarse fp16 steps (d = 40 / 8: the reference
+    lives in Q's pad channel, `MPAD`) and moved lazily (threshold 2^8); nothing may overflow the fp16 P operand or lose the row"""
+    b, hds, t = 1, 2, 512
+    c = hds * d
+    q = h16(randn((b, t, c), 540) * amp)
+    k = h16(randn((b, t, c), 541) * amp)
+    v = h16(randn((b, t, c), 542))
+    q[:, 7] = -q[:, 7].abs()                      # one query whose scores are all strongly negative against ...
+    k[:, :] = torch.where(torch.arange(t)[None, :, None] % 3 == 0, k.abs(), k)       # ... every third key
+    sp = lambda x: x.float().reshape(b, t, hds, d).permute(0, 2, 1, 3)
+    if d % 16 == 8:
+        # MPAD: the kernel multiplies Q by scale * log2 e ONCE and keeps it in fp16 (one more 2^-11 rounding per element of q, the size
+        # of the rounding q already carries); at |score| ~ 10^3 that moves near-tied keys, so the reference models the same operand
+        l2e = 1.4426950408889634
+        qs = (sp(q) * (d ** -0.5 * l2e)).half().float()
+        sim = torch.einsum("bhid,bhjd->bhij", qs, sp(k)) / l2e
+    else:
+        sim = torch.einsum("bhid,bhjd->bhij", sp(q), sp(k)) * d ** -0.5
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(v)).permute(0, 2, 1, 3).reshape(b, t, c)
+    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), hds)
+    assert torch.isfinite(o).all()
+    # near one-hot rows: the winner is decided by fp16-rounded operands on both sides; compare where the reference's top weight is clear
+    p = sim.softmax(-1)
+    top2 = p.topk(2, dim=-1).values
+    clear = ((top2[..., 0] - top2[..., 1]) > 0.5).permute(0, 2, 1)[..., None].expand(b, t, hds, d).reshape(b, t, c)
+    err = (o.float().cpu() - ref).abs()
+    assert float(err[clear].max()) < 2e-2, float(err[clear].max())
+
+
 def test_attention_long_sequence_spikes(ops):
     """the long-sequence kernel's deferred rescale: late dominant keys for queries of BOTH 32-query blocks of a wave, in
     both key halves of a tile and in the last tile (the rescale must follow the pending P V of the same block)"""
