@@ -474,13 +474,18 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(const AP p) {
     const f16* qp = p.q + ((size_t)b * p.Tq + (qvalid ? qrow : 0)) * p.ldq + h * D + c0;
 #pragma unroll
     for (int ks = 0; ks < KS16; ++ks)
-      qf[ks] = qvalid ? *reinterpret_cast<const f16x8*>(qp + (ks * 2 + lh) * 8) : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      qf[ks] = *reinterpret_cast<const f16x8*>(qp + (ks * 2 + lh) * 8);       // row 0 for queries past Tq: never stored
   }
 
   const f16* kbase = p.k + (size_t)b * p.TkS * p.ldk + h * D;
   const f16* vbase = p.v + (size_t)b * p.TkSv * p.ldv + h * D;
-  const int ntiles = (p.Tk + 31) / 32;
-  const f16x8 zero8 = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  // loop-invariant scalars pinned in SGPRs (see attention_kernel)
+  float sl2 = p.scale_log2;
+  int Tk = p.Tk;
+  unsigned ldk2 = (unsigned)p.ldk * 2u, ldv2 = (unsigned)p.ldv * 2u;
+  asm volatile("" : "+s"(sl2), "+s"(Tk), "+s"(ldk2), "+s"(ldv2));
+  const int ntiles = (Tk + 31) / 32;
+  const int last_key = Tk - 1;
   // K / V tiles are register-staged two tiles ahead (two register sets): with one workgroup per CU and one wave per SIMD nothing
   // else hides a global round trip, and one tile of compute (~1 us) is shorter than it (measured: 2.7 us per tile with the
   // loads issued one tile ahead)
@@ -491,10 +496,10 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(const AP p) {
     for (int i = 0; i < PASS; ++i) {
       const int it = tid + i * 256;
       const int row = it / CH, c = it - row * CH;
-      const int key = kt * 32 + row;
-      const bool ok = key < p.Tk;                            // rows >= Tk: K zero (masked anyway), V zero (P is 0 there)
-      kr[rs][i] = ok ? *reinterpret_cast<const f16x8*>(kbase + (size_t)key * p.ldk + c * 8) : zero8;
-      vr[rs][i] = ok ? *reinterpret_cast<const f16x8*>(vbase + (size_t)key * p.ldv + c * 8) : zero8;
+      // unconditional, counted loads (see attention_kernel): rows >= Tk re-read row Tk - 1, their keys are masked (P = 0, V finite)
+      const unsigned key = (unsigned)min(kt * 32 + row, last_key);
+      kr[rs][i] = *reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(kbase) + (__umul24(key, ldk2) + (unsigned)c * 16u));
+      vr[rs][i] = *reinterpret_cast<const f16x8*>(reinterpret_cast<const char*>(vbase) + (__umul24(key, ldv2) + (unsigned)c * 16u));
     }
   };
   auto store_tile = [&](auto SET, int stage) {
@@ -520,9 +525,11 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(const AP p) {
   float m_run = -INFINITY, l_run = 0.f;
 
   load_tile(S0{}, 0);
+  load_tile(S1{}, 1);                                 // set 1 carries the odd tiles, set 0 the even ones
   store_tile(S0{}, 0);
-  if (ntiles > 1) load_tile(S1{}, 1);                 // set 1 carries the odd tiles, set 0 the even ones
-  if (ntiles > 2) load_tile(S0{}, 2);
+#pragma unroll
+  for (int ks = 0; ks < KS16; ++ks) asm volatile("" : "+v"(qf[ks]));     // Q's wait in front of the loop (see attention_kernel)
+  load_tile(S0{}, 2);
   __syncthreads();
 
   auto compute = [&](int kt, int cur) __attribute__((always_inline)) {
@@ -561,32 +568,35 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(const AP p) {
       }
     }
     // ---- online softmax (base 2); key of s[r] = kt*32 + (r&3) + 8*(r>>2) + 4*lh
-    const bool tail = (kt + 1) * 32 > p.Tk;
     float mx = -INFINITY;
+    if ((kt + 1) * 32 > Tk) {                         // one uniform branch per tile
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (tail && kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh >= p.Tk) s[r] = -INFINITY;
-      mx = fmaxf(mx, s[r]);
+      for (int r = 0; r < 16; ++r)
+        if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh >= Tk) s[r] = -INFINITY;
     }
-    mx = xor32_max(mx);
-    const float m_new = fmaxf(m_run, mx * p.scale_log2);       // tile 0 always holds key 0: finite from the first tile on
-    float rs = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2, -m_new));
-      s[r] = pv;
-      rs += pv;
-    }
-    rs = xor32_sum(rs);
-    {
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    mx = xor32_max(mx) * sl2;
+    // lazy rescale of the running reference (threshold 2^8, see attention_kernel): O is DT x 16 registers per wave here, and the
+    // eager form multiplied all of them by alpha on every tile
+    if (__any(mx > m_run + 8.0f)) {                   // tile 0 always holds key 0: m_run becomes finite there
+      const float m_new = max_raw(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      l_run = l_run * alpha + rs;
+      l_run *= alpha;
 #pragma unroll
       for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
       m_run = m_new;
     }
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pv = __builtin_amdgcn_exp2f(fmaf(s[r], sl2, -m_run));
+      s[r] = pv;
+      rs += pv;
+    }
+    l_run += xor32_sum(rs);
     // ---- O^T[slice] += V[:, slice]^T P^T
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
@@ -606,17 +616,15 @@ __global__ __launch_bounds__(256, 1) void attention_wide_kernel(const AP p) {
   };
   // at the end of a tile the NEXT tile (loaded two iterations ago) goes from registers to the other LDS buffer and the freed
   // register set takes the loads of the tile after that; the closing barrier also frees the exchange area
-  for (int kt = 0; kt < ntiles; kt += 2) {
+  for (int kt = 0; kt < ntiles; kt += 2) {            // an odd tile count runs one fully masked tile (P = 0) at the end
     compute(kt, 0);
-    if (kt + 1 < ntiles) store_tile(S1{}, 1);
-    if (kt + 3 < ntiles) load_tile(S1{}, kt + 3);
+    store_tile(S1{}, 1);
+    load_tile(S1{}, kt + 3);
     __syncthreads();
-    if (kt + 1 < ntiles) {
-      compute(kt + 1, 1);
-      if (kt + 2 < ntiles) store_tile(S0{}, 0);
-      if (kt + 4 < ntiles) load_tile(S0{}, kt + 4);
-      __syncthreads();
-    }
+    compute(kt + 1, 1);
+    store_tile(S0{}, 0);
+    load_tile(S0{}, kt + 4);
+    __syncthreads();
   }
 
   if (qvalid) {
