@@ -70,6 +70,27 @@ __device__ __forceinline__ void kernarg_warm() {
   for (int i = 0; i < LINES; ++i) asm volatile("" ::"s"(v[i]));
 }
 
+// Sum over the 64 lanes of a wave, result in EVERY lane, without an LDS round trip per step (`__shfl_xor` compiles to ds_bpermute +
+// s_waitcnt, ~130 clocks each, six in a dependent chain): quad_perm DPP for the partners at distance 1 and 2, row rotations by 4 and 8
+// inside each row of 16 lanes, v_permlane16_swap / v_permlane32_swap (gfx950) across rows.  Fixed order, so results are reproducible;
+// the order differs from the xor butterfly, so the last bits may differ from a __shfl_xor reduction of the same values.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_move<0xB1>(v);                       // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);                       // quad_perm [2,3,0,1]
+  v += dpp_move<0x124>(v);                      // row_ror:4
+  v += dpp_move<0x128>(v);                      // row_ror:8 -> every lane holds its row's sum
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));     // rows (0,1) and (2,3) exchanged
+  v = a + b;
+  a = v; b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));     // halves exchanged
+  return a + b;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

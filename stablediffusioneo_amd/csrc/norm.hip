@@ -354,11 +354,8 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const GnPair gp, int Bper,
     float ts = 0.f, tq = 0.f;
     const float2* col = part_sq + (size_t)pair * P;
     for (int e = lane; e < P; e += 64) { ts += col[e].x; tq += col[e].y; }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      ts += __shfl_xor(ts, off, 64);
-      tq += __shfl_xor(tq, off, 64);
-    }
+    ts = wave_sum(ts);                            // DPP / permlane reduction: no LDS round trip per step (common.h)
+    tq = wave_sum(tq);
     if (lane == 0) tot[pair] = make_float2(ts, tq);
   }
   __syncthreads();
@@ -538,12 +535,6 @@ int groupnorm_nhwc(f16* y, int ldy, const f16* x, int ldx, const float* gamma, c
 // LayerNorm (`attention.py:372-374`, nn.LayerNorm eps 1e-5): one wave per row, the row lives in
 // registers (<= 4 vectors of 8 per lane => C <= 2048), exact two-pass mean / variance in fp32.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
 template <int VPL>
 __global__ __launch_bounds__(256) void layernorm_kernel(f16* __restrict__ y, int ldy, const f16* __restrict__ x, int ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
